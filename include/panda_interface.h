@@ -1,0 +1,201 @@
+/*
+ * panda_interface.h -- the drop-in C ABI of the MI355X-native MSM + NTT library.
+ *
+ * Every declaration in part 1 replaces, symbol for symbol and struct layout for struct layout,
+ * an `extern "C"` entry point of the reference's L2 shim so that the reference's Rust `gpu_ffi`
+ * (src/gpu_ffi/binding.rs:3-115) binds to this library unchanged:
+ *
+ *   reference declaration            src/cuda/core/panda_interface.cuh:10-110
+ *   reference definition             src/cuda/core/panda_interface.cu:11-191
+ *   Rust-side extern block           src/gpu_ffi/binding.rs:3-115
+ *   Rust-side repr(C) structs        src/gpu_ffi/common.rs:40-44,89-93,134-138,160-208
+ *
+ * Part 2 are the four symbols the Rust side declares but the reference never defines
+ * (binding.rs:14,16,54-56).  Part 3 is additive (no reference counterpart): BLS12-377,
+ * inverse NTT, multi-GPU and synthetic-input / diagnostics entry points.
+ *
+ * Conventions (unchanged from the reference):
+ *   - return value: the HIP runtime's error code cast to unsigned; 0 = success
+ *     (panda_interface.cuh:10-16; Rust only tests `!= 0`, unit.rs:55,79)
+ *   - handles are `{ void *handle; }` passed BY VALUE; handle = hipStream_t / hipEvent_t / hipMemPool_t
+ *   - configuration structs are passed BY VALUE (48 / 48 / 56 bytes)
+ *   - panda_msm_execute_* and panda_ntt_execute_* are synchronous on return
+ *   - field elements: little-endian u32 limbs in Montgomery form; scalar 32 B; BN254 affine
+ *     base 64 B (x||y, identity <=> x == 0); result 96 B X||Y||Z (Jacobian by default,
+ *     homogeneous X/Z,Y/Z when PROJECTIVE is requested), identity <=> Z == 0
+ *   - unlike the reference (msm_cuda.cuh:155, :554-555) the scalar buffer is never modified and
+ *     the device is the caller's current device, not a hard-coded device 0.
+ */
+#ifndef PANDA_INTERFACE_H
+#define PANDA_INTERFACE_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ part 1: reference ABI */
+
+typedef enum panda_error /* panda_interface.cuh:10-16 */
+{
+    panda_success = 0,
+    panda_error_invalid_value = 1,
+    panda_error_memory_allocation = 2,
+    panda_error_not_ready = 600
+} panda_error;
+
+typedef struct panda_stream { void *handle; } panda_stream;     /* panda_interface.cuh:18-21 */
+typedef struct panda_event { void *handle; } panda_event;       /* panda_interface.cuh:23-26 */
+typedef struct panda_mem_pool { void *handle; } panda_mem_pool; /* panda_interface.cuh:28-31 */
+
+typedef enum panda_msm_result_coordinate_type /* panda_interface.cuh:33-37 */
+{
+    JACOBIAN = 0,
+    PROJECTIVE,
+} panda_msm_result_coordinate_type;
+
+typedef void (*panda_host_fn)(void *user_data); /* panda_interface.cuh:39 */
+
+/* runtime shim -- panda_interface.cuh:40-68, panda_interface.cu:11-154 */
+panda_error panda_get_device_number(int *count);
+panda_error panda_get_device(int *device_id);
+panda_error panda_set_device(int device_id);
+panda_error panda_stream_create(panda_stream *stream, bool blocking_sync);
+panda_error panda_stream_wait_event(panda_stream stream, panda_event event);
+panda_error panda_stream_sync(panda_stream stream);
+panda_error panda_stream_destroy(panda_stream stream);
+panda_error panda_launch_host_fn(panda_stream stream, panda_host_fn fn, void *user_data);
+panda_error panda_event_create(panda_event *event, bool blocking_sync, bool disable_timing);
+panda_error panda_event_record(panda_event event, panda_stream stream);
+panda_error panda_event_sync(panda_event event);
+panda_error panda_event_query(panda_event event);
+panda_error panda_event_destroy(panda_event event);
+panda_error panda_mem_get_info(size_t *free, size_t *total);
+panda_error panda_malloc(void **ptr, size_t size);
+panda_error panda_malloc_host(void **ptr, size_t size);
+panda_error panda_free(void *ptr);
+panda_error panda_free_host(void *ptr);
+panda_error panda_host_register(void *ptr, size_t size);
+panda_error panda_host_unregister(void *ptr);
+panda_error panda_memcpy(void *dst, const void *src, size_t count);
+panda_error panda_memcpy_async(void *dst, const void *src, size_t count, panda_stream stream);
+panda_error panda_memset(void *ptr, int value, size_t count);
+panda_error panda_memset_async(void *ptr, int value, size_t count, panda_stream stream);
+panda_error panda_mem_pool_create(panda_mem_pool *pool, int device_id);
+panda_error panda_mem_pool_destroy(panda_mem_pool pool);
+panda_error panda_malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool pool, panda_stream stream);
+panda_error panda_free_async(void *ptr, panda_stream stream);
+
+typedef struct panda_msm_configuration /* panda_interface.cuh:70-79; Rust MSMConfiguration common.rs:168-185 */
+{
+    panda_mem_pool mem_pool;
+    panda_stream stream;
+    void *bases;   /* device: n affine points */
+    void *scalars; /* device: n Montgomery-form Fr; read-only here */
+    void *results; /* device or pinned host: 3 field elements */
+    unsigned log_scalars_count;
+    panda_msm_result_coordinate_type msm_result_coordinate_type;
+} panda_msm_configuration;
+typedef panda_msm_configuration msm_configuration;
+
+panda_error panda_msm_setup_bn254(void);                                               /* panda_interface.cu:152-155 */
+panda_error panda_msm_execute_bn254(const panda_msm_configuration exec_cfg);           /* panda_interface.cu:157-160 -> msm_cuda.cuh:551-784 */
+panda_error panda_msm_execute_bn254_host(const panda_msm_configuration exec_cfg);      /* panda_interface.cu:162-165 -> msm_host.cuh:267-383; all pointers host */
+panda_error panda_msm_tear_down(void);                                                 /* panda_interface.cu:167-170 */
+
+typedef struct panda_ntt_configuration /* panda_interface.cuh:86-94; Rust NTTConfiguration common.rs:187-196 */
+{
+    panda_mem_pool mem_pool;
+    panda_stream stream;
+    void *d_src;
+    void *d_dst;
+    unsigned log_n;
+    void *flag; /* host unsigned*: 0 -> result in d_src, 1 -> result in d_dst (fft.cu:211, unit.rs:521-532) */
+} panda_ntt_configuration;
+typedef panda_ntt_configuration ntt_configuration;
+
+typedef struct panda_ntt_configuration_v1 /* panda_interface.cuh:96-105; Rust NttconfigurationV1 common.rs:198-208 */
+{
+    panda_mem_pool mem_pool;
+    panda_stream stream;
+    void *d_src;
+    void *d_dst;
+    void *d_omega; /* HOST pointer to one Montgomery-form Fr: the primitive 2^log_n-th root (unit.rs:501-511) */
+    unsigned log_n;
+    void *flag;
+} panda_ntt_configuration_v1;
+typedef panda_ntt_configuration_v1 ntt_configuration_v1;
+
+panda_error panda_ntt_setup_bn254(void *input_omega);                                  /* panda_interface.cu:172-176 -> fft.cu:225-229 */
+panda_error panda_ntt_execute_bn254(panda_ntt_configuration exec_cfg);                 /* panda_interface.cu:178-181 -> fft.cu:231-242 */
+panda_error panda_ntt_tear_down(void);                                                 /* panda_interface.cu:188-191 */
+panda_error panda_ntt_execute_bn254_v1(const panda_ntt_configuration_v1 exec_cfg);     /* panda_interface.cu:183-186 -> fft.cu:244-260 */
+
+/* ------------------------------------------- part 2: declared by Rust, undefined in the reference */
+
+panda_error panda_stream_synchronize(panda_stream stream); /* binding.rs:14; used by PandaStream::sync, common.rs:71-76 */
+panda_error panda_stream_query(panda_stream stream);       /* binding.rs:16 (also declared in panda_interface.cuh:46) */
+panda_error panda_device_enable_peer_access(int device_id);  /* binding.rs:56 */
+panda_error panda_device_disable_peer_access(int device_id); /* binding.rs:54 */
+
+/* ------------------------------------------------------------------ part 3: additive entry points */
+
+/* BLS12-377 G1 MSM: bases 96 B affine, scalars 32 B, result 144 B (README.md:36 roadmap; BASELINE config 5) */
+panda_error panda_msm_setup_bls12_377(void);
+panda_error panda_msm_execute_bls12_377(const panda_msm_configuration exec_cfg);
+panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration exec_cfg);
+
+/* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
+panda_error panda_msm_set_window_bits(unsigned window_bits);
+/* per-phase device times of the last MSM on this thread, milliseconds; names via panda_msm_phase_name */
+#define PANDA_MSM_PHASES 8
+panda_error panda_msm_last_phase_ms(float *ms /* PANDA_MSM_PHASES floats */);
+const char *panda_msm_phase_name(unsigned phase);
+
+/* Inverse transform: runs the forward passes with omega^-1 and fuses the n^-1 scaling into the last pass.
+ * d_omega is the FORWARD root (host pointer), as for _v1. */
+panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exec_cfg);
+
+/* Multi-GPU, one process per GPU.  The exchange itself is the caller's (RCCL through
+ * torch.distributed or ncclAllGather): these are the per-rank halves either side of it.
+ *   MSM  : each rank runs panda_msm_execute_* on its base range -> one partial (96/144 B);
+ *          after the all-gather of partials every rank (or rank 0) calls panda_msm_combine_*.
+ *   NTT  : four-step over `ranks` slabs; see DESIGN.md section "multi-GPU". */
+panda_error panda_msm_combine_bn254(const void *partials /* host or device, count x 96 B Jacobian */, unsigned count,
+                                    panda_msm_result_coordinate_type out_type, void *result /* host, 96 B */);
+panda_error panda_msm_combine_bls12_377(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result);
+
+typedef struct panda_ntt_slab_configuration
+{
+    panda_stream stream;
+    void *d_slab;    /* device: this rank's rows, (n / ranks) elements */
+    void *d_scratch; /* device: same size */
+    void *omega;     /* HOST pointer: primitive n-th root, Montgomery form */
+    unsigned log_n;  /* global size */
+    unsigned log_ranks;
+    unsigned rank;
+    void *flag;      /* host unsigned*: which of d_slab / d_scratch holds the step's output */
+} panda_ntt_slab_configuration;
+/* step 1: local column transforms + inter-slab twiddle; step 2 (after the all-to-all): local row transforms */
+panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg);
+
+/* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377 */
+panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
+panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
+
+/* Element-wise diagnostics used by the parity tests: field id 0..3 = BN254 Fq, BN254 Fr, BLS12-377 Fq, BLS12-377 Fr;
+ * op 0..5 = add, sub, mul, sqr, to_montgomery, from_montgomery.  Device pointers. */
+panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);
+/* op 0 = Jacobian + affine (madd), 1 = Jacobian + Jacobian, 2 = double; Jacobian in/out */
+panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);
+
+const char *panda_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* PANDA_INTERFACE_H */
