@@ -1,0 +1,461 @@
+// fe29.h -- prime-field arithmetic on 29-bit limbs for gfx950 (and, unchanged, for the host).
+//
+// Replaces the reference's device field layer (src/cuda/core/field/field.cuh:139-486: 32-bit-limb
+// even/odd CIOS built on PTX mad.lo.cc/madc.hi.cc carry chains, asm/ptx.cuh) with a design
+// that fits CDNA4's integer pipe:
+//
+//   * gfx950 has no carry-chained multiply-add; its wide multiply is v_mad_u64_u32
+//     (32x32 + 64 -> 64, half rate, measured 46 lane-ops/clk/CU, profiles/r01_ubench_int_rates.txt).
+//   * so elements are held as N limbs of 29 bits in 32-bit registers ("unsaturated"): a column of
+//     the schoolbook product, N products of < 2^58 plus the N Montgomery products m_i*p_j, fits a
+//     64-bit accumulator without any carry handling.  A multiply is then 2*N^2 back-to-back
+//     v_mad_u64_u32 plus N (v_mul_lo, v_and) and 2N shifts: 925 cycles per wave for N = 9 against
+//     1700 for the 8x32 CIOS the compiler can build from the same instruction set.
+//   * Montgomery radix is R = 2^(29 N) (BN254: 2^261, R/p = 169).  The spare factor is spent on lazy
+//     reduction: products come back in [0, 2p); sums and differences are not reduced at all, only
+//     carry-normalised, as long as the bounds below hold.
+//
+// The wire format stays the reference's (Montgomery form with R_wire = 2^(32 L), 32-bit limbs,
+// field_storage.cuh:12-16); fe_from_wire / fe_to_wire convert with one extra multiply.
+//
+// Bounds contract (N = 9 figures; checked exhaustively by tests/host_check/fe29_check.cpp):
+//   limb classes   tight : limbs 0..N-2 <  2^29             (outputs of fe_mul / fe_sqr / fe_unpack)
+//                  loose : limbs 0..N-2 <= 2^29 + 8         (outputs of fe_norm / fe_sub / fe_add)
+//                  raw   : limbs 0..N-2 <  2^30 + 16        (fe_add_nr of two loose values)
+//   fe_mul(a, b)   needs  limb(a) < 2^30.5, limb(b) < 2^30  and  value(a) * value(b) < 0.9 R p
+//                  gives  tight, value < 2p  (exactly: < a b / R + p)
+//   fe_sub<KB>     needs  value(b) < KB p, limb(b) < 2^31 - 4; gives loose, value < value(a) + KEFF p
+#pragma once
+#include <stdint.h>
+
+#include "fe29_params.h"
+
+#if defined(__HIPCC__)
+#define PANDA_HD __host__ __device__ __forceinline__
+#else
+#define PANDA_HD inline __attribute__((always_inline))
+#endif
+
+#if defined(FE29_CHECK)
+#include <assert.h>
+#define FE29_SHADOW_DECL unsigned __int128 shadow = 0;
+#define FE29_SHADOW_MAC(x, y) shadow += (unsigned __int128)(x) * (y);
+#define FE29_SHADOW_SHIFT()                                      \
+    assert(shadow < ((unsigned __int128)1 << 64) && "fe29 column accumulator overflow"); \
+    shadow >>= 29;
+#else
+#define FE29_SHADOW_DECL
+#define FE29_SHADOW_MAC(x, y)
+#define FE29_SHADOW_SHIFT()
+#endif
+
+namespace panda29 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+constexpr u32 LIMB_BITS = 29;
+constexpr u32 LIMB_MASK = (1u << 29) - 1;
+
+template <class F>
+struct Fe {
+    u32 l[F::N];
+};
+
+template <class F>
+PANDA_HD void fe_zero(Fe<F> &r)
+{
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = 0;
+}
+
+template <class F>
+PANDA_HD void fe_one(Fe<F> &r)
+{
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = F::ONE[i];
+}
+
+template <class F>
+PANDA_HD void fe_const(Fe<F> &r, const u32 (&c)[F::N])
+{
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = c[i];
+}
+
+// all limbs zero (exact representation test, not a congruence test)
+template <class F>
+PANDA_HD bool fe_all_zero(const Fe<F> &a)
+{
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) acc |= a.l[i];
+    return acc == 0;
+}
+
+// r = a * b / R mod p.  Product scanning: column k of a*b and of m*p accumulate in one u64.
+template <class F>
+PANDA_HD void fe_mul(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    constexpr int N = F::N;
+    u32 m[N];
+    u32 out[N];
+    u64 acc = 0;
+    FE29_SHADOW_DECL
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_SHADOW_MAC(a.l[i], b.l[k - i])
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+            acc += (u64)m[i] * F::P[k - i];
+            FE29_SHADOW_MAC(m[i], F::P[k - i])
+        }
+        m[k] = ((u32)acc * F::INV) & LIMB_MASK;
+        acc += (u64)m[k] * F::P[0];
+        FE29_SHADOW_MAC(m[k], F::P[0])
+        acc >>= LIMB_BITS;
+        FE29_SHADOW_SHIFT()
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_SHADOW_MAC(a.l[i], b.l[k - i])
+        }
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (u64)m[i] * F::P[k - i];
+            FE29_SHADOW_MAC(m[i], F::P[k - i])
+        }
+        out[k - N] = (u32)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+        FE29_SHADOW_SHIFT()
+    }
+    out[N - 1] = (u32)acc;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+}
+
+// r = a^2 / R mod p; cross terms once, against the doubled operand.  limb(a) < 2^30.
+template <class F>
+PANDA_HD void fe_sqr(Fe<F> &r, const Fe<F> &a)
+{
+    constexpr int N = F::N;
+    u32 m[N], out[N], a2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a.l[i] << 1;
+    u64 acc = 0;
+    FE29_SHADOW_DECL
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) {
+            acc += (u64)a2[i] * a.l[k - i];
+            FE29_SHADOW_MAC(a2[i], a.l[k - i])
+        }
+        if ((k & 1) == 0) {
+            acc += (u64)a.l[k / 2] * a.l[k / 2];
+            FE29_SHADOW_MAC(a.l[k / 2], a.l[k / 2])
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+            acc += (u64)m[i] * F::P[k - i];
+            FE29_SHADOW_MAC(m[i], F::P[k - i])
+        }
+        m[k] = ((u32)acc * F::INV) & LIMB_MASK;
+        acc += (u64)m[k] * F::P[0];
+        FE29_SHADOW_MAC(m[k], F::P[0])
+        acc >>= LIMB_BITS;
+        FE29_SHADOW_SHIFT()
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; 2 * i < k; i++) {
+            acc += (u64)a2[i] * a.l[k - i];
+            FE29_SHADOW_MAC(a2[i], a.l[k - i])
+        }
+        if ((k & 1) == 0) {
+            acc += (u64)a.l[k / 2] * a.l[k / 2];
+            FE29_SHADOW_MAC(a.l[k / 2], a.l[k / 2])
+        }
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (u64)m[i] * F::P[k - i];
+            FE29_SHADOW_MAC(m[i], F::P[k - i])
+        }
+        out[k - N] = (u32)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+        FE29_SHADOW_SHIFT()
+    }
+    out[N - 1] = (u32)acc;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+}
+
+// one round of parallel carries: limbs < 2^32 in, loose out.  Value unchanged.
+template <class F>
+PANDA_HD void fe_norm(Fe<F> &r, const Fe<F> &t)
+{
+    constexpr int N = F::N;
+    u32 c[N];
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) c[i] = t.l[i] >> LIMB_BITS;
+    u32 o[N];
+    o[0] = t.l[0] & LIMB_MASK;
+#pragma unroll
+    for (int i = 1; i < N - 1; i++) o[i] = (t.l[i] & LIMB_MASK) + c[i - 1];
+    o[N - 1] = t.l[N - 1] + c[N - 2];
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = o[i];
+}
+
+// limb-wise sum, no carries ("raw")
+template <class F>
+PANDA_HD void fe_add_nr(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = a.l[i] + b.l[i];
+}
+
+template <class F>
+PANDA_HD void fe_add(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    Fe<F> t;
+    fe_add_nr(t, a, b);
+    fe_norm(r, t);
+}
+
+// extra multiples of p a subtraction must add so that its top limb cannot underflow
+template <class F>
+struct SubMargin {
+    // top limb of p in units of 1: BN254-like fields have ~2^21 there, the 14-limb BLS12-377 Fq < 1
+    static constexpr int value = (F::P[F::N - 1] >= 16) ? 1 : 6;
+};
+
+// r = a - b + KEFF*p, b < KB*p.  Result loose.
+template <class F, int KB>
+PANDA_HD void fe_sub(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    constexpr int K = KB + SubMargin<F>::value;
+    static_assert(K <= 40, "subtraction constant table too small");
+    Fe<F> t;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+#if defined(FE29_CHECK)
+        assert((u64)a.l[i] + F::KP[K][i] >= b.l[i] && (u64)a.l[i] + F::KP[K][i] - b.l[i] < (1ull << 32) && "fe_sub limb range");
+#endif
+        t.l[i] = a.l[i] + F::KP[K][i] - b.l[i];
+    }
+    fe_norm(r, t);
+}
+
+// value bound added by fe_sub<F,KB>, in units of p
+template <class F, int KB>
+struct SubGrowth {
+    static constexpr int value = F::KEFF[KB + SubMargin<F>::value];
+};
+
+// r = KEFF*p - a  (negation), a < KB*p
+template <class F, int KB>
+PANDA_HD void fe_neg(Fe<F> &r, const Fe<F> &a)
+{
+    constexpr int K = KB + SubMargin<F>::value;
+    Fe<F> t;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+#if defined(FE29_CHECK)
+        assert(F::KP[K][i] >= a.l[i] && "fe_neg limb range");
+#endif
+        t.l[i] = F::KP[K][i] - a.l[i];
+    }
+    fe_norm(r, t);
+}
+
+// 32-bit wire limbs -> 29-bit limbs (same integer); tight
+template <class F>
+PANDA_HD void fe_unpack(Fe<F> &r, const u32 *w)
+{
+    constexpr int N = F::N, L = F::L;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int bit = 29 * k, wi = bit >> 5, sh = bit & 31;
+        u32 v = 0;
+        if (wi < L) {
+            v = w[wi] >> sh;
+            if (sh > 3 && wi + 1 < L) v |= w[wi + 1] << (32 - sh);
+        }
+        r.l[k] = (k < N - 1) ? (v & LIMB_MASK) : v;
+    }
+}
+
+// 29-bit limbs -> 32-bit wire limbs; input must be canonical-tight (all limbs < 2^29, value < 2^(32 L))
+template <class F>
+PANDA_HD void fe_pack(u32 *w, const Fe<F> &a)
+{
+    constexpr int N = F::N, L = F::L;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int bit = 32 * i, j = bit / 29, s = bit - 29 * j;
+        u32 v = a.l[j] >> s;
+        if (j + 1 < N) v |= a.l[j + 1] << (29 - s);
+        if (29 - s + 29 < 32 && j + 2 < N) v |= a.l[j + 2] << (58 - s);
+        w[i] = v;
+    }
+}
+
+// sequential carry propagation: any limbs < 2^32 -> tight (value unchanged)
+template <class F>
+PANDA_HD void fe_carry(Fe<F> &a)
+{
+#pragma unroll
+    for (int i = 0; i < F::N - 1; i++) {
+        a.l[i + 1] += a.l[i] >> LIMB_BITS;
+        a.l[i] &= LIMB_MASK;
+    }
+}
+
+// tight value in [0, 2p) -> canonical [0, p)
+template <class F>
+PANDA_HD void fe_reduce_once(Fe<F> &a)
+{
+    constexpr int N = F::N;
+    u32 d[N];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u32 t = a.l[i] - F::P[i] - borrow;
+        borrow = t >> 31;
+        d[i] = (i < N - 1) ? (t & LIMB_MASK) : t;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) a.l[i] = borrow ? a.l[i] : d[i];
+}
+
+// any value within the fe_mul input contract -> canonical [0, p), same residue
+template <class F>
+PANDA_HD void fe_canon(Fe<F> &r, const Fe<F> &a)
+{
+    Fe<F> one;
+    fe_one(one);
+    fe_mul(r, a, one); // a * R / R, now tight and < 2p
+    fe_reduce_once(r);
+}
+
+// residue zero?  (one multiply; used only on rare paths)
+template <class F>
+PANDA_HD bool fe_is_zero_mod_p(const Fe<F> &a)
+{
+    Fe<F> t;
+    fe_canon(t, a);
+    return fe_all_zero(t);
+}
+
+// tight value in [0, 2p): is it 0 or p?
+template <class F>
+PANDA_HD bool fe_is_zero_2p(const Fe<F> &a)
+{
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+        z |= a.l[i];
+        e |= a.l[i] ^ F::P[i];
+    }
+    return z == 0 || e == 0;
+}
+
+// wire (x * 2^(32L) mod p, 32-bit limbs) -> internal (x * 2^(29N) mod p), tight, < 2p
+template <class F>
+PANDA_HD void fe_from_wire(Fe<F> &r, const u32 *w)
+{
+    Fe<F> t, k;
+    fe_unpack(t, w);
+    fe_const(k, F::K_IN);
+    fe_mul(r, t, k);
+}
+
+// internal -> wire, canonical
+template <class F>
+PANDA_HD void fe_to_wire(u32 *w, const Fe<F> &a)
+{
+    Fe<F> t, k;
+    fe_const(k, F::K_OUT);
+    fe_mul(t, a, k);
+    fe_reduce_once(t);
+    fe_pack(w, t);
+}
+
+// wire Montgomery scalar -> canonical integer (32-bit limbs out)
+template <class F>
+PANDA_HD void fe_wire_to_canonical(u32 *out, const u32 *w)
+{
+    Fe<F> t, k, c;
+    fe_unpack(t, w);
+    fe_const(k, F::K_CANON);
+    fe_mul(c, t, k);
+    fe_reduce_once(c);
+    fe_pack(out, c);
+}
+
+// canonical small integer -> internal form
+template <class F>
+PANDA_HD void fe_from_u32(Fe<F> &r, u32 v)
+{
+    Fe<F> t, k;
+    fe_zero(t);
+    t.l[0] = v & LIMB_MASK;
+    t.l[1] = v >> LIMB_BITS;
+    fe_const(k, F::K_TOINT);
+    fe_mul(r, t, k);
+}
+
+template <class F>
+PANDA_HD void fe_select(Fe<F> &r, bool c, const Fe<F> &a, const Fe<F> &b)
+{
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+}
+
+// a^e for a 64-bit exponent (host-side helpers, twiddle setup)
+template <class F>
+PANDA_HD void fe_pow_u64(Fe<F> &r, const Fe<F> &a, u64 e)
+{
+    Fe<F> acc, base = a;
+    fe_one(acc);
+    while (e) {
+        if (e & 1) fe_mul(acc, acc, base);
+        fe_sqr(base, base);
+        e >>= 1;
+    }
+    r = acc;
+}
+
+// a^(p-2): inverse by Fermat (host side / rare device paths)
+template <class F>
+PANDA_HD void fe_inv(Fe<F> &r, const Fe<F> &a)
+{
+    // exponent p - 2 from the 32-bit limb table
+    u32 e[F::L];
+#pragma unroll
+    for (int i = 0; i < F::L; i++) e[i] = F::PW[i];
+    u32 borrow = 2;
+#pragma unroll
+    for (int i = 0; i < F::L; i++) {
+        u32 t = e[i] - borrow;
+        borrow = e[i] < borrow ? 1u : 0u;
+        e[i] = t;
+    }
+    Fe<F> acc, base = a;
+    fe_one(acc);
+    for (int bit = 0; bit < F::BITS; bit++) {
+        if ((e[bit >> 5] >> (bit & 31)) & 1) fe_mul(acc, acc, base);
+        fe_sqr(base, base);
+    }
+    r = acc;
+}
+
+} // namespace panda29

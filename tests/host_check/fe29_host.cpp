@@ -1,0 +1,110 @@
+// Host build of the product's fe29.h / curve29.h with FE29_CHECK instrumentation (128-bit shadow
+// accumulators, limb-range asserts).  Test infrastructure: compiled by tests/test_fe29_host.py with g++.
+#define FE29_CHECK 1
+#include "../../panda_amd/csrc/curve29.h"
+
+#include <stddef.h>
+#include <string.h>
+
+using namespace panda29;
+
+template <class F>
+static void field_op(int op, u32 *r, const u32 *a, const u32 *b, size_t n)
+{
+    constexpr int L = F::L;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> x, y, z;
+        if (op == 4) { // to_montgomery: canonical in -> wire Montgomery out
+            Fe<F> t, k;
+            fe_unpack(t, a + i * L);
+            fe_const(k, F::K_TOINT);
+            fe_mul(x, t, k); // internal form of the canonical integer
+            fe_to_wire(r + i * L, x);
+            continue;
+        }
+        if (op == 5) { // from_montgomery
+            fe_wire_to_canonical<F>(r + i * L, a + i * L);
+            continue;
+        }
+        fe_from_wire(x, a + i * L);
+        if (b) fe_from_wire(y, b + i * L);
+        switch (op) {
+        case 0: fe_add(z, x, y); break;
+        case 1: fe_sub<F, 2>(z, x, y); break;
+        case 2: fe_mul(z, x, y); break;
+        case 3: fe_sqr(z, x); break;
+        case 6: fe_inv(z, x); break;
+        }
+        fe_to_wire(r + i * L, z);
+    }
+}
+
+// Jacobian wire in/out; b is affine wire for op 0
+template <class F>
+static void curve_op(int op, u32 *r, const u32 *a, const u32 *b, size_t n)
+{
+    constexpr int L = F::L;
+    for (size_t i = 0; i < n; i++) {
+        Xyzz<F> p, q;
+        xyzz_from_jacobian_wire(p, a + i * 3 * L);
+        if (op == 0) {
+            Fe<F> x, y;
+            bool inf = affine_from_wire(x, y, b + i * 2 * L);
+            xyzz_madd(p, x, y, inf);
+        } else if (op == 1) {
+            xyzz_from_jacobian_wire(q, b + i * 3 * L);
+            xyzz_add(p, q);
+        } else {
+            xyzz_dbl(q, p);
+            p = q;
+        }
+        xyzz_to_jacobian_wire(r + i * 3 * L, p);
+    }
+}
+
+// acc = sum_i (+/-) base_i, one long dependent chain (stresses the lazy bounds); signs bit i of `neg`
+template <class F>
+static void chain(u32 *r, const u32 *bases, const unsigned char *neg, size_t n, int homogeneous)
+{
+    constexpr int L = F::L;
+    Xyzz<F> acc;
+    xyzz_set_identity(acc);
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> x, y, ny;
+        bool inf = affine_from_wire(x, y, bases + i * 2 * L);
+        if (neg && neg[i]) {
+            fe_neg_tight2p(ny, y);
+            y = ny;
+        }
+        xyzz_madd(acc, x, y, inf);
+    }
+    if (homogeneous)
+        xyzz_to_homogeneous_wire(r, acc);
+    else
+        xyzz_to_jacobian_wire(r, acc);
+}
+
+extern "C" {
+int h29_field_op(int field_id, int op, u32 *r, const u32 *a, const u32 *b, size_t n)
+{
+    switch (field_id) {
+    case 0: field_op<Bn254Fq>(op, r, a, b, n); return 0;
+    case 1: field_op<Bn254Fr>(op, r, a, b, n); return 0;
+    case 2: field_op<Bls377Fq>(op, r, a, b, n); return 0;
+    case 3: field_op<Bls377Fr>(op, r, a, b, n); return 0;
+    }
+    return 1;
+}
+int h29_curve_op(int curve, int op, u32 *r, const u32 *a, const u32 *b, size_t n)
+{
+    if (curve == 0) curve_op<Bn254Fq>(op, r, a, b, n);
+    else curve_op<Bls377Fq>(op, r, a, b, n);
+    return 0;
+}
+int h29_chain(int curve, u32 *r, const u32 *bases, const unsigned char *neg, size_t n, int homogeneous)
+{
+    if (curve == 0) chain<Bn254Fq>(r, bases, neg, n, homogeneous);
+    else chain<Bls377Fq>(r, bases, neg, n, homogeneous);
+    return 0;
+}
+}

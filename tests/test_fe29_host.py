@@ -1,0 +1,141 @@
+"""The product's field/curve headers (panda_amd/csrc/fe29.h, curve29.h) compiled for the HOST with
+FE29_CHECK instrumentation (128-bit shadow column accumulators, limb-range asserts) and compared
+with the oracle.  This is the CPU-side sanitizer run for the arithmetic the HIP kernels execute."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as po
+import pyref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_check", "fe29_host.cpp")
+SO = os.path.join(HERE, "host_check", "libfe29_host.so")
+CSRC = os.path.join(os.path.dirname(HERE), "panda_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def h29():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("fe29.h", "curve29.h", "fe29_params.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", SO, SRC], check=True)
+    return C.CDLL(SO)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def test_params_header_is_current():
+    out = subprocess.run(["python3", os.path.join(CSRC, "gen_params.py")], check=True, capture_output=True, text=True).stdout
+    assert out == open(os.path.join(CSRC, "fe29_params.h")).read()
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_field_ops(h29, fid):
+    lc = po.FIELD_LC[fid]
+    info = po.field_info(fid)
+    mod = pyref.limbs_to_int(info["p"])
+    rng = np.random.default_rng(100 + fid)
+    vals = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (1 << (mod.bit_length() - 1)), (1 << (mod.bit_length() - 1)) - 1]
+    vals += [int.from_bytes(rng.bytes(4 * lc), "little") % mod for _ in range(3000)]
+    # adversarial limb patterns: all 29-bit limbs at their maximum below p
+    vals += [min(mod - 1, sum(((1 << 29) - 1) << (29 * i) for i in range(k))) for k in range(1, 14)]
+    a = np.stack([pyref.int_to_limbs(v, lc) for v in vals])
+    b = np.stack([pyref.int_to_limbs(v, lc) for v in reversed(vals)])
+    for op in (po.OP_ADD, po.OP_SUB, po.OP_MUL, po.OP_SQR, po.OP_TO_MONT, po.OP_FROM_MONT):
+        r = np.empty_like(a)
+        assert h29.h29_field_op(fid, op, _p(r), _p(a), _p(b), C.c_size_t(len(vals))) == 0
+        want = po.f_vec(fid, op, a, b)
+        assert (r == want).all(), op
+    r = np.empty_like(a[:40])
+    h29.h29_field_op(fid, po.OP_INV, _p(r), _p(a[:40]), None, C.c_size_t(40))
+    assert (r == po.f_vec(fid, po.OP_INV, a[:40])).all()
+
+
+def _affine_all(cid, jac):
+    return np.stack([po.to_affine(cid, j) for j in jac])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_curve_ops(h29, cid):
+    lc = po.LC_Q[cid]
+    n = 200
+    g = po.generator(cid)
+    bases = po.gen_bases(cid, 42 + cid, n)
+    scal = po.gen_scalars(po.FR_OF[cid], 43 + cid, n)
+    # random Jacobian points with non-trivial Z: k_i * G
+    jac = np.stack([po.scalar_mul(cid, g, pyref.int_to_limbs(pyref.limbs_to_int(s) % pyref.CURVES[cid].r, 8)) for s in scal[:n]])
+    ident = np.zeros(3 * lc, dtype=np.uint32)
+    aff_of_jac = _affine_all(cid, jac)
+    negy = aff_of_jac.copy()
+    negy[:, lc:] = po.f_vec(po.FQ_OF[cid], po.OP_SUB, np.zeros_like(negy[:, lc:]), negy[:, lc:])
+    bz = bases.copy()
+    bz[::3, :lc] = 0  # identity bases
+    cases_madd = [(jac, bases), (jac, aff_of_jac), (jac, negy), (np.tile(ident, (n, 1)), bases), (jac, bz)]
+    for A, B in cases_madd:
+        r = np.empty_like(A)
+        h29.h29_curve_op(cid, 0, _p(r), _p(np.ascontiguousarray(A)), _p(np.ascontiguousarray(B)), C.c_size_t(n))
+        want = po.curve_vec(cid, po.COP_MADD, A, B)
+        assert (_affine_all(cid, r) == _affine_all(cid, want)).all()
+        assert ((r[:, 2 * lc:] == 0).all(axis=1) == (want[:, 2 * lc:] == 0).all(axis=1)).all()
+    neg_jac = jac.copy()
+    neg_jac[:, lc:2 * lc] = po.f_vec(po.FQ_OF[cid], po.OP_SUB, np.zeros_like(jac[:, lc:2 * lc]), jac[:, lc:2 * lc])
+    for A, B in [(jac, jac[::-1].copy()), (jac, jac), (jac, neg_jac), (np.tile(ident, (n, 1)), jac), (jac, np.tile(ident, (n, 1)))]:
+        r = np.empty_like(A)
+        h29.h29_curve_op(cid, 1, _p(r), _p(np.ascontiguousarray(A)), _p(np.ascontiguousarray(B)), C.c_size_t(n))
+        want = po.curve_vec(cid, po.COP_ADD, A, B)
+        assert (_affine_all(cid, r) == _affine_all(cid, want)).all()
+    r = np.empty_like(jac)
+    h29.h29_curve_op(cid, 2, _p(r), _p(jac), None, C.c_size_t(n))
+    assert (_affine_all(cid, r) == _affine_all(cid, po.curve_vec(cid, po.COP_DBL, jac))).all()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_long_madd_chain_with_signs(h29, cid):
+    """2000 dependent mixed additions with random signs, repeated and cancelling bases: the lazy
+    bounds (X < 9p, Y < 5p ...) must hold along the whole chain (asserts inside the library)."""
+    lc = po.LC_Q[cid]
+    c = pyref.CURVES[cid]
+    n = 2000
+    seed = 7 + cid
+    bases = po.gen_bases(cid, seed, n)
+    bases[100:110] = bases[99]          # repeated base -> doubling branch
+    bases[500] = bases[499]
+    rng = np.random.default_rng(5)
+    neg = rng.integers(0, 2, n).astype(np.uint8)
+    neg[100:110] = neg[99]
+    neg[500] = 1 - neg[499]             # P + (-P)
+    bases[700, :lc] = 0                 # identity base
+    out = np.empty(3 * lc, dtype=np.uint32)
+    for hom in (0, 1):
+        h29.h29_chain(cid, _p(out), _p(bases), _p(neg), C.c_size_t(n), hom)
+        # expected via multipliers: sum (+/-) m_i
+        k = 0
+        for i in range(n):
+            if i == 700:
+                continue
+            src = i
+            if 100 <= i < 110:
+                src = 99
+            if i == 500:
+                src = 499
+            m = po.gen_multiplier(seed, src)
+            k += -m if neg[i] else m
+        want = pyref.encode_affine(c, pyref.ec_mul(c, k % c.r, c.g))
+        got = po.hom_to_affine(cid, out) if hom else po.to_affine(cid, out)
+        assert (got == want).all()
+
+
+def test_k13_all_equal_bases_chain(h29, golden_dir):
+    # every step after the first is the P + P / general madd mix the reference's fixture exercises
+    g = po.generator(0)
+    n = 300
+    bases = np.tile(g, (n, 1))
+    out = np.empty(24, dtype=np.uint32)
+    h29.h29_chain(0, _p(out), _p(bases), None, C.c_size_t(n), 0)
+    c = pyref.CURVES[0]
+    assert (po.to_affine(0, out) == pyref.encode_affine(c, pyref.ec_mul(c, n, c.g))).all()
