@@ -263,6 +263,18 @@ PANDA_HD void xyzz_to_homogeneous_wire(u32 *out, const Xyzz<F> &p)
     fe_to_wire(out + 2 * L, z);
 }
 
+// non-identity XYZZ -> affine in internal form (tight, < 2p): one inversion, 1/ZZ = (ZZ/ZZZ)^2
+template <class F>
+PANDA_HD void xyzz_to_affine_internal(Fe<F> &x, Fe<F> &y, const Xyzz<F> &p)
+{
+    Fe<F> zi3, t, zi2;
+    fe_inv(zi3, p.ZZZ);
+    fe_mul(t, p.ZZ, zi3);
+    fe_sqr(zi2, t);
+    fe_mul(x, p.X, zi2);
+    fe_mul(y, p.Y, zi3);
+}
+
 // Jacobian wire triple -> XYZZ (X, Y, Z^2, Z^3)
 template <class F>
 PANDA_HD void xyzz_from_jacobian_wire(Xyzz<F> &p, const u32 *in)

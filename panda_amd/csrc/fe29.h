@@ -31,7 +31,7 @@
 #include "fe29_params.h"
 
 #if defined(__HIPCC__)
-#define PANDA_HD __host__ __device__ __forceinline__
+#define PANDA_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define PANDA_HD inline __attribute__((always_inline))
 #endif
@@ -242,7 +242,7 @@ template <class F, int KB>
 PANDA_HD void fe_sub(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
 {
     constexpr int K = KB + SubMargin<F>::value;
-    static_assert(K <= 40, "subtraction constant table too small");
+    static_assert(K <= 200, "subtraction constant table too small");
     Fe<F> t;
 #pragma unroll
     for (int i = 0; i < F::N; i++) {
@@ -334,6 +334,27 @@ PANDA_HD void fe_reduce_once(Fe<F> &a)
     }
 #pragma unroll
     for (int i = 0; i < N; i++) a.l[i] = borrow ? a.l[i] : d[i];
+}
+
+// limbs < 2^32, value < 2^9 p  ->  canonical [0, p), without a multiply.
+// The quotient is estimated from the top limb with a 2^-52 fixed-point reciprocal of (top limb of p) + 1,
+// which never overshoots and undershoots by at most one; needs a field whose p has a wide top limb.
+template <class F>
+PANDA_HD void fe_reduce_small(Fe<F> &a)
+{
+    constexpr int N = F::N;
+    static_assert(F::P[N - 1] >= (1u << 16), "fe_reduce_small: top limb of p too narrow for the quotient estimate");
+    fe_carry(a);
+    constexpr u64 C = (1ull << 52) / ((u64)F::P[N - 1] + 1);
+    const u32 m = (u32)(((u64)a.l[N - 1] * C) >> 52);
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        int64_t t = (int64_t)a.l[i] - (int64_t)((u64)m * F::P[i]) + carry;
+        a.l[i] = (i < N - 1) ? ((u32)t & LIMB_MASK) : (u32)t;
+        carry = t >> LIMB_BITS;
+    }
+    fe_reduce_once(a);
 }
 
 // any value within the fe_mul input contract -> canonical [0, p), same residue
@@ -451,9 +472,13 @@ PANDA_HD void fe_inv(Fe<F> &r, const Fe<F> &a)
     }
     Fe<F> acc, base = a;
     fe_one(acc);
-    for (int bit = 0; bit < F::BITS; bit++) {
-        if ((e[bit >> 5] >> (bit & 31)) & 1) fe_mul(acc, acc, base);
-        fe_sqr(base, base);
+#pragma unroll
+    for (int w = 0; w < F::L; w++) { // words statically indexed: no scratch on the device
+        u32 ew = e[w];
+        for (int b = 0; b < 32; b++) {
+            if ((ew >> b) & 1) fe_mul(acc, acc, base);
+            fe_sqr(base, base);
+        }
     }
     r = acc;
 }

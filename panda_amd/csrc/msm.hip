@@ -1,0 +1,647 @@
+// msm.hip -- Pippenger multi-scalar multiplication for gfx950.
+//
+// Drop-in for the reference's GPU path behind panda_msm_execute_bn254
+// (src/cuda/core/unit/msm/msm_cuda.cuh:551-784), redesigned rather than translated:
+//
+//   reference (msm_cuda.cuh)                           here
+//   ------------------------------------------------   -----------------------------------------------
+//   scalars de-Montgomeryed IN PLACE (:148-157)        digits kernel reads scalars, never writes them
+//   unsigned c-bit digits, 2^c - 1 buckets/window      signed digits, 2^(c-1) buckets/window (base negation is free)
+//   one thread per bucket walks its list (:373-409)    flat chunks of K sorted entries per thread: every thread does
+//     -> collapses on skewed scalars                     exactly K mixed adds whatever the bucket sizes; bucket pieces
+//                                                        cut by a chunk boundary are merged by a fix-up kernel
+//   each bucket weighted by c doublings + adds         segmented running sums (2 adds per bucket) + one short
+//     (:411-420, ~240 mulmods per bucket)                double-and-add per 4 buckets + tree reduction
+//   Jacobian madd 7M+4S on 8x32-bit PTX carry chains   XYZZ madd 8M+2S on 9x29-bit limbs / v_mad_u64_u32 (fe29.h)
+//   9 cudaDeviceSynchronize per call (:611-755)        one stream, one synchronisation before the host Horner
+//   scratch cudaMallocAsync'd and freed per call       per-thread arena kept between calls
+//
+// Pipeline (all on cfg.stream):
+//   k_convert_bases   wire affine -> internal Montgomery radix, 64 B/point (96 B BLS12-377)
+//   k_digits          scalar -> canonical -> W signed c-bit digits (u16 codes, window-major)
+//   k_count           histogram of (window, bucket)
+//   k_scan            exclusive scan per window -> bucket offsets, cursors
+//   k_scatter         point ids (+ sign) into bucket order
+//   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
+//   k_fixup           merge bucket pieces that straddle chunks
+//   k_reduce_groups   4 buckets -> one weighted partial
+//   k_tree_reduce     partials -> one point per window
+//   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743), output conversion
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "curve29.h"
+#include "panda_internal.h"
+
+using namespace panda29;
+
+namespace panda {
+
+// ---------------------------------------------------------------- arena
+hipError_t Arena::reserve(size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (base && (dev != device || bytes > capacity)) {
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        e = hipFree(base);
+        if (e != hipSuccess) return e;
+        base = nullptr;
+        capacity = 0;
+    }
+    if (!base) {
+        size_t want = bytes + (bytes >> 3) + (1u << 20);
+        e = hipMalloc(&base, want);
+        if (e != hipSuccess) {
+            base = nullptr;
+            return e;
+        }
+        capacity = want;
+        device = dev;
+    }
+    used = 0;
+    return hipSuccess;
+}
+
+hipError_t Arena::release()
+{
+    hipError_t e = hipSuccess;
+    if (base) {
+        (void)hipDeviceSynchronize();
+        e = hipFree(base);
+    }
+    base = nullptr;
+    capacity = used = 0;
+    device = -1;
+    return e;
+}
+
+Arena &thread_arena()
+{
+    static thread_local Arena arena;
+    return arena;
+}
+
+hipError_t release_thread_arena() { return thread_arena().release(); }
+
+} // namespace panda
+
+namespace {
+
+constexpr u32 DIGIT_ZERO = 0x7fffu; // "+2^15" cannot occur with the recoding below, so it encodes digit 0
+constexpr int GROUP = 4;            // buckets per k_reduce_groups thread
+
+struct CurveBn254 {
+    typedef Bn254Fq Fq;
+    typedef Bn254Fr Fr;
+};
+struct CurveBls377 {
+    typedef Bls377Fq Fq;
+    typedef Bls377Fr Fr;
+};
+
+// ------------------------------------------------------------------------------- HBM layouts
+// XYZZ point: 4*N u32, array of structs (144 B for N = 9, 224 B for N = 14; both multiples of 16).
+template <class F>
+__device__ __forceinline__ void store_xyzz(u32 *dst, const Xyzz<F> &p)
+{
+    constexpr int N = F::N;
+    u32 tmp[4 * N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        tmp[i] = p.X.l[i];
+        tmp[N + i] = p.Y.l[i];
+        tmp[2 * N + i] = p.ZZ.l[i];
+        tmp[3 * N + i] = p.ZZZ.l[i];
+    }
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < N; i++) d4[i] = make_uint4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
+}
+
+template <class F>
+__device__ __forceinline__ void load_xyzz(Xyzz<F> &p, const u32 *src)
+{
+    constexpr int N = F::N;
+    u32 tmp[4 * N];
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint4 v = s4[i];
+        tmp[4 * i] = v.x;
+        tmp[4 * i + 1] = v.y;
+        tmp[4 * i + 2] = v.z;
+        tmp[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        p.X.l[i] = tmp[i];
+        p.Y.l[i] = tmp[N + i];
+        p.ZZ.l[i] = tmp[2 * N + i];
+        p.ZZZ.l[i] = tmp[3 * N + i];
+    }
+}
+
+template <int WORDS>
+__device__ __forceinline__ void load_words(u32 *dst, const u32 *src)
+{
+    static_assert(WORDS % 4 == 0, "vector loads");
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; i++) {
+        uint4 v = s4[i];
+        dst[4 * i] = v.x;
+        dst[4 * i + 1] = v.y;
+        dst[4 * i + 2] = v.z;
+        dst[4 * i + 3] = v.w;
+    }
+}
+
+template <int WORDS>
+__device__ __forceinline__ void store_words(u32 *dst, const u32 *src)
+{
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; i++) d4[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------------------- kernels
+
+// wire affine (Montgomery radix 2^(32L)) -> internal radix 2^(29N), canonical, packed in 2*L words.
+// A wire identity (x == 0, affine.cuh:72-75) becomes all zeros.
+template <class F>
+__global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ wire, u32 *__restrict__ out, u64 n)
+{
+    constexpr int L = F::L;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[2 * L], o[2 * L];
+    load_words<2 * L>(w, wire + i * 2 * L);
+    Fe<F> x, y;
+    bool inf = affine_from_wire(x, y, w);
+    fe_reduce_once(x);
+    fe_reduce_once(y);
+    fe_pack(o, x);
+    fe_pack(o + L, y);
+    if (inf) {
+#pragma unroll
+        for (int k = 0; k < 2 * L; k++) o[k] = 0;
+    }
+    store_words<2 * L>(out + i * 2 * L, o);
+}
+
+// scalar (Montgomery wire form) -> W signed digits.  code = (neg << 15) | (|d| - 1), DIGIT_ZERO for d = 0.
+// Replaces init_handle_scalars_kernel + the slice extraction of calc_lens/fill_arrs (msm_cuda.cuh:148-205,232-282).
+template <class Fr>
+__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ dig, u64 n, unsigned c, unsigned W)
+{
+    constexpr int L = Fr::L;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[L], s[L + 1];
+    load_words<L>(w, scalars + i * L);
+    fe_wire_to_canonical<Fr>(s, w);
+    s[L] = 0;
+    const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+    u32 carry = 0;
+    for (unsigned k = 0; k < W; k++) {
+        unsigned lo = k * c, m = lo >> 5, sh = lo & 31;
+        u32 raw = 0;
+        if (m < (unsigned)L) {
+            u64 v = s[m] | ((u64)s[m + 1] << 32);
+            raw = (u32)(v >> sh) & mask;
+        }
+        raw += carry;
+        u32 code;
+        if (raw >= half) { // negative digit raw - 2^c (or zero when raw == 2^c)
+            u32 mag = full - raw;
+            carry = 1;
+            code = mag ? (0x8000u | (mag - 1)) : DIGIT_ZERO;
+        } else {
+            carry = 0;
+            code = raw ? (raw - 1) : DIGIT_ZERO;
+        }
+        dig[(u64)k * n + i] = (uint16_t)code;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_count(const uint16_t *__restrict__ dig, u32 *__restrict__ count, u64 total, unsigned log_n, unsigned NB)
+{
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    u32 code = dig[e];
+    if (code == DIGIT_ZERO) return;
+    u32 w = (u32)(e >> log_n);
+    atomicAdd(&count[(u64)w * NB + (code & 0x7fffu)], 1u);
+}
+
+// one block per window: exclusive scan of NB counts -> off[w][0..NB], cursor[w][b] = off[w][b]
+__global__ void __launch_bounds__(1024) k_scan(const u32 *__restrict__ count, u32 *__restrict__ off, u32 *__restrict__ cursor, unsigned NB)
+{
+    __shared__ u32 part[1024];
+    const unsigned w = blockIdx.x, t = threadIdx.x;
+    const unsigned per = (NB + 1023) / 1024;
+    const u32 *cw = count + (u64)w * NB;
+    u32 *ow = off + (u64)w * (NB + 1);
+    u32 *uw = cursor + (u64)w * NB;
+    u32 local = 0;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned b = t * per + j;
+        if (b < NB) local += cw[b];
+    }
+    part[t] = local;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - local;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned b = t * per + j;
+        if (b < NB) {
+            ow[b] = run;
+            uw[b] = run;
+            run += cw[b];
+        }
+    }
+    if (t == 1023) ow[NB] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_scatter(const uint16_t *__restrict__ dig, u32 *__restrict__ cursor, u32 *__restrict__ sorted, u64 total,
+                                                 unsigned log_n, unsigned NB)
+{
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    u32 code = dig[e];
+    if (code == DIGIT_ZERO) return;
+    u32 w = (u32)(e >> log_n);
+    u32 i = (u32)(e & (((u64)1 << log_n) - 1));
+    u32 pos = atomicAdd(&cursor[(u64)w * NB + (code & 0x7fffu)], 1u);
+    sorted[((u64)w << log_n) + pos] = i | ((code & 0x8000u) << 16);
+}
+
+// first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
+__device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
+{
+    u32 lo = 0, hi = NB; // invariant: off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+template <class F>
+__device__ __forceinline__ void load_base(Fe<F> &x, Fe<F> &y, bool &inf, const u32 *bases, u32 entry)
+{
+    constexpr int L = F::L;
+    u32 w[2 * L];
+    load_words<2 * L>(w, bases + (u64)(entry & 0x7fffffffu) * 2 * L);
+    u32 nz = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L; k++) nz |= w[k];
+    inf = (nz == 0);
+    fe_unpack(x, w);
+    fe_unpack(y, w + L);
+    if (entry >> 31) {
+        Fe<F> ny;
+        fe_neg<F, 1>(ny, y); // y is canonical (< p)
+        y = ny;
+    }
+}
+
+// The hot kernel.  Thread t of window w owns sorted entries [t*K, t*K + K) of that window and adds the
+// bases they name into the accumulators of the buckets they fall in; the first and last bucket of a
+// chunk may continue in the neighbouring chunks, those pieces go to `parts` and are merged by k_fixup.
+// Replaces aggerate_buckets_groups_kernel's per-bucket list walk (msm_cuda.cuh:373-409).
+template <class F>
+__global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
+                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, unsigned log_n, unsigned NB, unsigned K,
+                                                    unsigned chunks)
+{
+    constexpr int PW = 4 * F::N;
+    const unsigned w = blockIdx.y;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= chunks) return;
+    const u32 *ow = off + (u64)w * (NB + 1);
+    const u32 nw = ow[NB];
+    const u32 start = t * K;
+    if (start >= nw) return;
+    const u32 end = min(start + K, nw);
+    const u32 *sw = sorted + ((u64)w << log_n);
+    u32 *pw = parts + ((u64)w * chunks + t) * 2 * PW;
+    u32 *bw = bucket_acc + (u64)w * NB * PW;
+
+    u32 b = owner_bucket(ow, NB, start);
+    u32 next = ow[b + 1];
+    Xyzz<F> acc;
+    xyzz_set_identity(acc);
+
+    Fe<F> x, y;
+    bool inf;
+    load_base<F>(x, y, inf, bases, sw[start]);
+    for (u32 pos = start; pos < end; pos++) {
+        if (pos >= next) { // the run of bucket b ends here
+            const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
+            store_xyzz<F>(complete ? bw + (u64)b * PW : pw, acc);
+            xyzz_set_identity(acc);
+            do {
+                b++;
+                next = ow[b + 1];
+            } while (next <= pos);
+        }
+        Fe<F> cx = x, cy = y;
+        const bool cinf = inf;
+        if (pos + 1 < end) load_base<F>(x, y, inf, bases, sw[pos + 1]); // prefetch the next base under this madd
+        xyzz_madd(acc, cx, cy, cinf);
+    }
+    // last run: complete only if the bucket both starts and ends inside the chunk
+    const bool starts_inside = ow[b] >= start;
+    const bool ends_inside = next <= end;
+    u32 *dst = (starts_inside && ends_inside) ? bw + (u64)b * PW : (starts_inside ? pw + PW : pw);
+    store_xyzz<F>(dst, acc);
+}
+
+// bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
+// also is t0's first run and started earlier -- impossible here since t0 = start / K), the ONLY run of every
+// chunk strictly between (slot 0) and the FIRST run of t1 (slot 0).
+template <class F>
+__global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB,
+                                               unsigned K, unsigned chunks)
+{
+    constexpr int PW = 4 * F::N;
+    const unsigned w = blockIdx.y;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    const u32 *ow = off + (u64)w * (NB + 1);
+    const u32 s = ow[b], e = ow[b + 1];
+    if (s == e) return; // empty: bucket_acc was zeroed (identity)
+    const u32 t0 = s / K, t1 = (e - 1) / K;
+    if (t0 == t1) return; // lies inside one chunk: written by k_accumulate
+    const u32 *pw = parts + (u64)w * chunks * 2 * PW;
+    Xyzz<F> acc, q;
+    load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
+    for (u32 t = t0 + 1; t <= t1; t++) {
+        load_xyzz<F>(q, pw + (u64)t * 2 * PW);
+        xyzz_add(acc, q);
+    }
+    store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+}
+
+// k * p for a small scalar k (double-and-add from the top bit)
+template <class F>
+__device__ __forceinline__ void xyzz_mul_small(Xyzz<F> &r, const Xyzz<F> &p, u32 k)
+{
+    Xyzz<F> acc, d;
+    xyzz_set_identity(acc);
+    if (k == 0 || xyzz_is_identity(p)) {
+        r = acc;
+        return;
+    }
+    int top = 31 - __clz(k);
+    for (int bit = top; bit >= 0; bit--) {
+        xyzz_dbl(d, acc);
+        acc = d;
+        if ((k >> bit) & 1) xyzz_add(acc, p);
+    }
+    r = acc;
+}
+
+// thread (w, g): buckets b = g*GROUP .. g*GROUP+GROUP-1, weights b+1.
+//   running sums from the top give S = sum B_j and T = sum (j+1) B_j (j local); the partial is T + (g*GROUP) * S.
+// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420.
+template <class F>
+__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ out, unsigned NB, unsigned groups)
+{
+    constexpr int PW = 4 * F::N;
+    const unsigned w = blockIdx.y;
+    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const u32 *bw = bucket_acc + (u64)w * NB * PW;
+    Xyzz<F> run, sum, q;
+    xyzz_set_identity(run);
+    xyzz_set_identity(sum);
+    for (int j = GROUP - 1; j >= 0; j--) {
+        u32 b = g * GROUP + j;
+        if (b < NB) {
+            load_xyzz<F>(q, bw + (u64)b * PW);
+            xyzz_add(run, q);
+        }
+        xyzz_add(sum, run);
+    }
+    xyzz_mul_small(q, run, g * GROUP);
+    xyzz_add(sum, q);
+    store_xyzz<F>(out + ((u64)w * groups + g) * PW, sum);
+}
+
+// block b of window w sums in[w][b*per .. b*per+per) -> out[w][b]
+template <class F>
+__global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned count, unsigned per)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
+    const unsigned w = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+    const unsigned begin = blk * per, end = min(begin + per, count);
+    Xyzz<F> acc, q;
+    xyzz_set_identity(acc);
+    for (unsigned i = begin + t; i < end; i += 256) {
+        load_xyzz<F>(q, in + ((u64)w * count + i) * PW);
+        xyzz_add(acc, q);
+    }
+    store_xyzz<F>(lds + t * PW, acc);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            load_xyzz<F>(q, lds + (t + s) * PW);
+            xyzz_add(acc, q);
+            store_xyzz<F>(lds + t * PW, acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz<F>(out + ((u64)w * gridDim.x + blk) * PW, acc);
+}
+
+// ------------------------------------------------------------------------------- host side
+
+thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
+unsigned g_window_override = 0;
+
+const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "count+scan", "scatter", "accumulate",
+                                                   "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
+
+// window width policy (replaces get_window_bits_count, msm_cuda.cuh:21-45)
+unsigned pick_window_bits(unsigned log_n)
+{
+    if (g_window_override) return std::min(std::max(g_window_override, 2u), 16u);
+    int c = (int)log_n - 4;
+    return (unsigned)std::min(std::max(c, 4), 16);
+}
+
+template <class F>
+void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, unsigned c)
+{
+    Xyzz<F> acc, d;
+    xyzz_set_identity(acc);
+    for (int w = (int)windows.size() - 1; w >= 0; w--) {
+        for (unsigned k = 0; k < c; k++) {
+            xyzz_dbl(d, acc);
+            acc = d;
+        }
+        xyzz_add(acc, windows[w]);
+    }
+    result = acc;
+}
+
+template <class C>
+hipError_t msm_execute(const panda_msm_configuration &cfg)
+{
+    typedef typename C::Fq Fq;
+    typedef typename C::Fr Fr;
+    constexpr int PW = 4 * Fq::N;
+    constexpr int LQ = Fq::L, LR = Fr::L;
+    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
+    const unsigned log_n = cfg.log_scalars_count;
+    if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;
+    const u64 n = (u64)1 << log_n;
+    const unsigned c = pick_window_bits(log_n);
+    const unsigned W = (Fr::BITS + 1 + c - 1) / c; // one spare bit for the signed-digit carry
+    const unsigned NB = 1u << (c - 1);
+    const unsigned K = log_n >= 22 ? 64 : (log_n >= 16 ? 32 : 16);
+    const unsigned chunks = (unsigned)((n + K - 1) / K);
+    const unsigned groups = (NB + GROUP - 1) / GROUP;
+    const unsigned lvl1 = (groups + 255) / 256 > 64 ? 64 : (groups + 255) / 256; // blocks in the first tree level
+    const unsigned per1 = (groups + lvl1 - 1) / lvl1;
+
+    // ---- scratch
+    const size_t sz_bases = panda::align256(n * 2 * LQ * 4);
+    const size_t sz_dig = panda::align256(n * W * 2);
+    const size_t sz_count = panda::align256((size_t)W * NB * 4);
+    const size_t sz_off = panda::align256((size_t)W * (NB + 1) * 4);
+    const size_t sz_sorted = panda::align256(n * W * 4);
+    const size_t sz_bacc = panda::align256((size_t)W * NB * PW * 4);
+    const size_t sz_parts = panda::align256((size_t)W * chunks * 2 * PW * 4);
+    const size_t sz_gsum = panda::align256((size_t)W * groups * PW * 4);
+    const size_t sz_l1 = panda::align256((size_t)W * lvl1 * PW * 4);
+    const size_t sz_win = panda::align256((size_t)W * PW * 4);
+    panda::Arena &arena = panda::thread_arena();
+    PANDA_TRY(arena.reserve(sz_bases + sz_dig + 2 * sz_count + sz_off + sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + 4096));
+    u32 *d_bases = (u32 *)arena.take(sz_bases);
+    uint16_t *d_dig = (uint16_t *)arena.take(sz_dig);
+    u32 *d_count = (u32 *)arena.take(sz_count);
+    u32 *d_cursor = (u32 *)arena.take(sz_count);
+    u32 *d_off = (u32 *)arena.take(sz_off);
+    u32 *d_sorted = (u32 *)arena.take(sz_sorted);
+    u32 *d_bacc = (u32 *)arena.take(sz_bacc);
+    u32 *d_parts = (u32 *)arena.take(sz_parts);
+    u32 *d_gsum = (u32 *)arena.take(sz_gsum);
+    u32 *d_l1 = (u32 *)arena.take(sz_l1);
+    u32 *d_win = (u32 *)arena.take(sz_win);
+    if (!d_win) return hipErrorOutOfMemory;
+
+    hipEvent_t ev[8];
+    for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
+    auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
+
+    PANDA_TRY(mark(0));
+    const unsigned blocks_n = (unsigned)((n + 255) / 256);
+    const u64 total = n * W;
+    const unsigned blocks_total = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
+    hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, c, W);
+    PANDA_TRY(mark(1));
+    PANDA_TRY(hipMemsetAsync(d_count, 0, sz_count, stream));
+    hipLaunchKernelGGL(k_count, dim3(blocks_total), dim3(256), 0, stream, d_dig, d_count, total, log_n, NB);
+    hipLaunchKernelGGL(k_scan, dim3(W), dim3(1024), 0, stream, d_count, d_off, d_cursor, NB);
+    PANDA_TRY(mark(2));
+    hipLaunchKernelGGL(k_scatter, dim3(blocks_total), dim3(256), 0, stream, d_dig, d_cursor, d_sorted, total, log_n, NB);
+    PANDA_TRY(mark(3));
+    PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
+    hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, W), dim3(128), 0, stream, d_bases, d_sorted, d_off, d_bacc, d_parts, log_n, NB, K,
+                       chunks);
+    PANDA_TRY(mark(4));
+    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, W), dim3(128), 0, stream, d_off, d_parts, d_bacc, NB, K, chunks);
+    PANDA_TRY(mark(5));
+    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, W), dim3(128), 0, stream, d_bacc, d_gsum, NB, groups);
+    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(lvl1, W), dim3(256), 0, stream, d_gsum, d_l1, groups, per1);
+    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(1, W), dim3(256), 0, stream, d_l1, d_win, lvl1, lvl1);
+    PANDA_TRY(mark(6));
+    PANDA_TRY(hipGetLastError());
+
+    std::vector<u32> h_win((size_t)W * PW);
+    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, (size_t)W * PW * 4, hipMemcpyDeviceToHost, stream));
+    PANDA_TRY(hipStreamSynchronize(stream));
+
+    std::vector<Xyzz<Fq>> windows(W);
+    for (unsigned w = 0; w < W; w++) {
+        const u32 *src = h_win.data() + (size_t)w * PW;
+        for (int i = 0; i < Fq::N; i++) {
+            windows[w].X.l[i] = src[i];
+            windows[w].Y.l[i] = src[Fq::N + i];
+            windows[w].ZZ.l[i] = src[2 * Fq::N + i];
+            windows[w].ZZZ.l[i] = src[3 * Fq::N + i];
+        }
+    }
+    Xyzz<Fq> result;
+    host_horner(result, windows, c);
+    u32 out[3 * LQ];
+    if (cfg.msm_result_coordinate_type == PROJECTIVE)
+        xyzz_to_homogeneous_wire(out, result);
+    else
+        xyzz_to_jacobian_wire(out, result);
+    // results may be a device pointer (unit.rs:32-47) or pinned host memory (msm_test.cu:53,125)
+    PANDA_TRY(hipMemcpyAsync(cfg.results, out, sizeof(out), hipMemcpyDefault, stream));
+    PANDA_TRY(mark(7));
+    PANDA_TRY(hipStreamSynchronize(stream));
+
+    float ms = 0;
+    for (int i = 0; i < 6; i++) {
+        hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+        g_phase_ms[i] = ms;
+    }
+    hipEventElapsedTime(&ms, ev[6], ev[7]);
+    g_phase_ms[6] = ms;
+    hipEventElapsedTime(&ms, ev[0], ev[6]);
+    g_phase_ms[7] = ms;
+    for (auto &e : ev) hipEventDestroy(e);
+    (void)LR;
+    return hipSuccess;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------- C ABI
+
+extern "C" {
+
+panda_error panda_msm_setup_bn254(void) { return panda_success; }
+panda_error panda_msm_setup_bls12_377(void) { return panda_success; }
+
+panda_error panda_msm_tear_down(void) { return static_cast<panda_error>(panda::release_thread_arena()); }
+
+panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute<CurveBn254>(cfg)); }
+
+panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute<CurveBls377>(cfg)); }
+
+panda_error panda_msm_set_window_bits(unsigned window_bits)
+{
+    if (window_bits > 16) return panda_error_invalid_value;
+    g_window_override = window_bits;
+    return panda_success;
+}
+
+panda_error panda_msm_last_phase_ms(float *ms)
+{
+    if (!ms) return panda_error_invalid_value;
+    for (int i = 0; i < PANDA_MSM_PHASES; i++) ms[i] = g_phase_ms[i];
+    return panda_success;
+}
+
+const char *panda_msm_phase_name(unsigned phase) { return phase < PANDA_MSM_PHASES ? kPhaseNames[phase] : ""; }
+
+} // extern "C"

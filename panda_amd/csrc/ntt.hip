@@ -1,0 +1,527 @@
+// ntt.hip -- radix-2 Cooley-Tukey number-theoretic transform over BN254 Fr for gfx950.
+//
+// Drop-in for panda_ntt_execute_bn254[_v1] (src/cuda/core/unit/ntt/fft.cu:171-260).  The reference ships the
+// driver only -- its kernel bodies are compiled out (fft.cu:18-35,89-101,117-168) -- so what is kept is
+//   * the transform the commented-out code defines: natural order in, natural order out,
+//     y[k] = sum_j x[j] w^(jk), Montgomery-form residues, no 1/n scaling;
+//   * the buffer protocol: ceil(log_n / 8) passes of radix 2^deg (deg = min(8, remaining), fft.cu:177,193-210),
+//     ping-pong between d_src and d_dst, *flag = passes & 1 tells the caller where the answer is (fft.cu:211,
+//     unit.rs:521-532).
+// and everything else is new:
+//   * one workgroup = one 1024-element tile (4 radix-256 sub-transforms) held in LDS as 9 limb planes, so a
+//     butterfly's 18 ds_read_b32 / ds_write_b32 are bank-conflict-free across the wave;
+//   * the residues stay in the caller's Montgomery radix (2^256): multiplying by a twiddle held in the
+//     kernels' own radix (2^261, fe29.h) maps wire form to wire form, so no conversion pass exists;
+//   * butterfly twiddles (128 per pass) are staged in LDS; the inter-pass twiddles w^(e k i) come from two
+//     L2-resident power tables (<= 2^16 and <= 2^12 entries) and one multiply, never from an n-entry table;
+//   * sums are never reduced inside a pass: bounds are tracked at compile time and one multiply-free
+//     reduction (fe_reduce_small) is inserted where the lazy headroom (R/p = 169) would run out;
+//   * the inverse transform folds n^-1 into the last pass's twiddle table.
+//
+// Multi-GPU (no reference counterpart): n = G m over G ranks.  Rank r holds the decimated slab
+// X_r[j2] = x[r + G j2].  step1 = local m-point transform with root w^G, then the twiddle w^(r k2);
+// the caller's all-to-all moves chunk q (k2 in [q m/G, (q+1) m/G)) to rank q; step2 = m/G transforms of
+// size G with root w^m down the received pieces.  Rank q ends with y[k1 m + q m/G + k2'] at [k1][k2'].
+#include <algorithm>
+#include <mutex>
+#include <string.h>
+
+#include "fe29.h"
+#include "panda_internal.h"
+
+using namespace panda29;
+
+namespace {
+
+typedef Bn254Fr Fr;
+constexpr int NL = Fr::N;       // 9 limbs
+constexpr int TW_STRIDE = 12;   // table entries padded to 48 B for 16-byte loads
+constexpr int TILE = 1024;      // elements per workgroup
+constexpr long long LIM = Fr::HEADROOM * 9 / 10;
+
+struct PowBase {
+    u32 pw[16][NL]; // base^(2^j), canonical internal form
+    u32 scale[NL];  // optional factor folded into every entry
+    int has_scale;
+};
+
+// out[t] = base^t (* scale), canonical, t < count
+__global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u32 *__restrict__ out)
+{
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    Fe<Fr> acc, f;
+    if (pb.has_scale) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) acc.l[i] = pb.scale[i];
+    } else
+        fe_one(acc);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if ((t >> j) & 1) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
+            fe_mul(acc, acc, f);
+        }
+    }
+    fe_reduce_once(acc); // ONE and products are < 2p tight
+    u32 *dst = out + (size_t)t * TW_STRIDE;
+#pragma unroll
+    for (int i = 0; i < NL; i++) dst[i] = acc.l[i];
+#pragma unroll
+    for (int i = NL; i < TW_STRIDE; i++) dst[i] = 0;
+}
+
+__device__ __forceinline__ void load_tw(Fe<Fr> &r, const u32 *__restrict__ tab, unsigned idx)
+{
+    const uint4 *s = reinterpret_cast<const uint4 *>(tab + (size_t)idx * TW_STRIDE);
+    uint4 a = s[0], b = s[1], c = s[2];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
+}
+
+__device__ __forceinline__ void load_elem(Fe<Fr> &v, const u32 *__restrict__ src)
+{
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 lo = s4[0], hi = s4[1];
+    u32 w8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    fe_unpack(v, w8);
+}
+
+// canonical element -> 32 bytes
+__device__ __forceinline__ void store_elem(u32 *__restrict__ dst, const Fe<Fr> &v)
+{
+    u32 w8[8];
+    fe_pack(w8, v);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    d4[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+    d4[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+}
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); }
+
+// LDS image of field elements as NL limb planes of STRIDE words: lane e of a wave touches word e of each plane
+template <int STRIDE>
+struct Planes {
+    u32 *base;
+    __device__ __forceinline__ void load(Fe<Fr> &r, unsigned e) const
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + e];
+    }
+    __device__ __forceinline__ void store(const Fe<Fr> &r, unsigned e) const
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++) base[i * STRIDE + e] = r.l[i];
+    }
+};
+typedef Planes<TILE> TilePlanes;
+typedef Planes<128> TwiddlePlanes;
+
+// Rounds RND..DEG-1 of the radix-2^DEG sub-transform; BC = bound (units of p) of every element in LDS.
+template <int DEG, int RND, int BC>
+struct Rounds {
+    static constexpr bool REDUCE = (2 * BC + 1) >= LIM; // (a - b + (BC+1) p) * twiddle must stay below 0.9 R p
+    static constexpr int B0 = REDUCE ? 1 : BC;
+    static constexpr int FINAL = Rounds<DEG, RND + 1, 2 * B0 + 1>::FINAL;
+    __device__ __forceinline__ static void run(const TilePlanes &u, const TwiddlePlanes &pq, unsigned blk_base, unsigned t)
+    {
+        constexpr unsigned R = 1u << DEG;
+        constexpr unsigned bit = (R >> 1) >> RND;
+        const unsigned di = t & (bit - 1);
+        const unsigned i0 = (t << 1) - di, i1 = i0 + bit;
+        Fe<Fr> a, b, s, d;
+        u.load(a, blk_base + i0);
+        u.load(b, blk_base + i1);
+        if (REDUCE) {
+            fe_reduce_small(a);
+            fe_reduce_small(b);
+        }
+        fe_add(s, a, b);
+        fe_sub<Fr, B0>(d, a, b);
+        if (di != 0) {
+            Fe<Fr> w;
+            pq.load(w, di << RND);
+            fe_mul(d, d, w);
+        }
+        u.store(s, blk_base + i0);
+        u.store(d, blk_base + i1);
+        __syncthreads();
+        Rounds<DEG, RND + 1, 2 * B0 + 1>::run(u, pq, blk_base, t);
+    }
+};
+template <int DEG, int BC>
+struct Rounds<DEG, DEG, BC> {
+    static constexpr int FINAL = BC;
+    __device__ __forceinline__ static void run(const TilePlanes &, const TwiddlePlanes &, unsigned, unsigned) {}
+};
+
+struct PassArgs {
+    const u32 *x;
+    u32 *y;
+    const u32 *pq;  // 2^(DEG-1) butterfly twiddles
+    const u32 *ta;  // (w^e)^t, t < 2^la
+    const u32 *tb;  // (w^(e 2^16))^t
+    unsigned log_n;
+    unsigned lgp;
+    unsigned la;          // bits of m = k*i served by ta
+    unsigned force_tw;    // multiply by ta[0] even when m == 0 (ta carries the n^-1 factor)
+    unsigned tile_elems;  // min(TILE, n)
+    unsigned strided_out; // write output i of sub-transform blk to blk + i*S (the input's own layout)
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
+{
+    constexpr unsigned R = 1u << DEG;
+    __shared__ u32 s_u[NL * TILE];
+    __shared__ u32 s_pq[NL * 128];
+    const TilePlanes u{s_u};
+    const TwiddlePlanes pq{s_pq};
+    const unsigned tid = threadIdx.x;
+    const unsigned TE = A.tile_elems;
+    const unsigned B = TE >> DEG;              // sub-transforms in this tile
+    const unsigned S = (1u << A.log_n) >> DEG; // stride between the inputs of one sub-transform
+    const unsigned p = 1u << A.lgp;
+    const unsigned blk0 = blockIdx.x * B;
+
+    if (tid < (R >> 1)) {
+        Fe<Fr> w;
+        load_tw(w, A.pq, tid);
+        pq.store(w, tid);
+    }
+    for (unsigned e = tid; e < TE; e += 512) {
+        const unsigned b = e % B, i = e / B;
+        const unsigned blk = blk0 + b;
+        Fe<Fr> v;
+        load_elem(v, A.x + ((size_t)blk + (size_t)i * S) * 8);
+        if (A.lgp != 0 || A.force_tw) {
+            const unsigned k = blk & (p - 1);
+            const unsigned m = k * i;
+            if (m != 0 || A.force_tw) {
+                Fe<Fr> tw;
+                load_tw(tw, A.ta, m & ((1u << A.la) - 1));
+                if ((m >> A.la) != 0) {
+                    Fe<Fr> t2;
+                    load_tw(t2, A.tb, m >> A.la);
+                    fe_mul(tw, tw, t2);
+                }
+                fe_mul(v, v, tw);
+            }
+        }
+        u.store(v, b * R + i);
+    }
+    __syncthreads();
+
+    // butterflies: thread -> (sub-transform, butterfly index)
+    const unsigned half = R >> 1;
+    const unsigned sub = tid / half, t = tid % half;
+    const bool active = tid < (TE >> 1);
+    // every thread passes the DEG barriers of the rounds; threads beyond a short tile only wait
+    if (active)
+        Rounds<DEG, 0, 2>::run(u, pq, sub * R, t);
+    else
+        for (int r = 0; r < DEG; r++) __syncthreads();
+
+    constexpr int FB = Rounds<DEG, 0, 2>::FINAL;
+    static_assert(FB < 256, "final bound must fit fe_reduce_small");
+    for (unsigned e = tid; e < TE; e += 512) {
+        unsigned b, i;
+        size_t dst_index;
+        if (A.strided_out) {
+            b = e % B;
+            i = e / B;
+            dst_index = (size_t)(blk0 + b) + (size_t)i * S;
+        } else if (A.lgp == 0) {
+            b = e / R;
+            i = e % R;
+            dst_index = ((size_t)(blk0 + b) << DEG) + i;
+        } else {
+            b = e % B;
+            i = e / B;
+            const unsigned blk = blk0 + b, k = blk & (p - 1);
+            dst_index = ((size_t)(blk - k) << DEG) + k + (size_t)i * p;
+        }
+        Fe<Fr> v;
+        u.load(v, b * R + bitrev(i, DEG));
+        fe_reduce_small(v);
+        store_elem(A.y + dst_index * 8, v);
+    }
+}
+
+// x[i] *= ta[i & 0xffff] * tb[i >> 16]   (the inter-slab twiddle w^(r k2) of the multi-GPU transform)
+__global__ void __launch_bounds__(256) k_slab_twiddle(u32 *__restrict__ x, const u32 *__restrict__ ta, const u32 *__restrict__ tb, unsigned count)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<Fr> v, tw;
+    load_elem(v, x + (size_t)i * 8);
+    load_tw(tw, ta, i & 0xffffu);
+    if (i >> 16) {
+        Fe<Fr> t2;
+        load_tw(t2, tb, i >> 16);
+        fe_mul(tw, tw, t2);
+    }
+    fe_mul(v, v, tw);
+    fe_reduce_once(v);
+    store_elem(x + (size_t)i * 8, v);
+}
+
+// ------------------------------------------------------------------------------- host side
+
+std::mutex g_omega_mutex;
+u32 g_omega_wire[8];
+bool g_omega_set = false;
+
+const size_t SZ_TA = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
+const size_t SZ_TB = panda::align256((size_t)(1u << 12) * TW_STRIDE * 4);
+const size_t SZ_PQ = panda::align256((size_t)128 * TW_STRIDE * 4);
+
+void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
+{
+    Fe<Fr> cur = base;
+    for (int j = 0; j < 16; j++) {
+        Fe<Fr> c = cur;
+        fe_reduce_once(c);
+        for (int i = 0; i < NL; i++) pb.pw[j][i] = c.l[i];
+        fe_sqr(cur, cur);
+    }
+    pb.has_scale = scale ? 1 : 0;
+    for (int i = 0; i < NL; i++) pb.scale[i] = scale ? scale->l[i] : 0;
+}
+
+void build_table(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, unsigned count, u32 *d_out)
+{
+    PowBase pb;
+    fill_pow_base(pb, base, scale);
+    hipLaunchKernelGGL(k_pow_table, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, d_out);
+}
+
+void launch_pass(unsigned deg, const PassArgs &a, unsigned tiles, hipStream_t s)
+{
+    switch (deg) {
+    case 1: hipLaunchKernelGGL(k_ntt_pass<1>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_ntt_pass<2>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_ntt_pass<3>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_ntt_pass<4>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(k_ntt_pass<5>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 6: hipLaunchKernelGGL(k_ntt_pass<6>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 7: hipLaunchKernelGGL(k_ntt_pass<7>, dim3(tiles), dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_ntt_pass<8>, dim3(tiles), dim3(512), 0, s, a); break;
+    }
+}
+
+// The caller's earlier work on other (blocking) streams must be visible: the reference runs its passes on the
+// legacy NULL stream (fft.cu:201), which implies exactly this dependency.
+hipError_t order_after_null_stream(hipStream_t stream)
+{
+    hipEvent_t ev;
+    PANDA_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PANDA_TRY(hipEventRecord(ev, nullptr));
+    PANDA_TRY(hipStreamWaitEvent(stream, ev, 0));
+    PANDA_TRY(hipEventDestroy(ev));
+    return hipSuccess;
+}
+
+// All passes of one local transform of size 2^log_n with root `omega` (internal form).  `scale`, when given,
+// multiplies every output (folded into the last pass's twiddles).  Leaves the result in src when *passes_out
+// is even, in dst when odd; enqueues only.
+hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
+                      unsigned *passes_out)
+{
+    const u64 n = (u64)1 << log_n;
+    unsigned log_p = 0, passes = 0;
+    const unsigned max_deg = log_n < 8 ? log_n : 8; // MAX_LOG2_RADIX, fft.cu:9,177
+    const unsigned total_passes = (log_n + 7) / 8;
+    while (log_p < log_n) {
+        const unsigned deg = std::min(max_deg, log_n - log_p);
+        const bool last = (passes + 1 == total_passes);
+        u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB), *d_pq = (u32 *)arena.take(SZ_PQ);
+        if (!d_ta || !d_tb || !d_pq) return hipErrorOutOfMemory;
+        PassArgs a{};
+        a.x = src;
+        a.y = dst;
+        a.pq = d_pq;
+        a.ta = d_ta;
+        a.tb = d_tb;
+        a.log_n = log_n;
+        a.lgp = log_p;
+        a.tile_elems = (unsigned)std::min<u64>(TILE, n);
+        const unsigned mbits = log_p + deg; // bits of m = k * i
+        a.la = log_p == 0 ? 16 : std::min(16u, mbits);
+        a.force_tw = (scale && last) ? 1 : 0;
+        a.strided_out = 0;
+        Fe<Fr> base;
+        fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
+        build_table(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
+        if (log_p != 0) {
+            fe_pow_u64(base, omega, n >> log_p >> deg);
+            build_table(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
+            if (mbits > 16) {
+                Fe<Fr> base_b;
+                fe_pow_u64(base_b, base, (u64)1 << 16);
+                build_table(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
+            }
+        } else if (a.force_tw) {
+            fe_one(base);
+            build_table(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
+        }
+        launch_pass(deg, a, (unsigned)(n / a.tile_elems), stream);
+        PANDA_TRY(hipGetLastError());
+        const u32 *tmp = dst;
+        dst = const_cast<u32 *>(src);
+        src = tmp;
+        log_p += deg;
+        passes++;
+    }
+    *passes_out = passes;
+    return hipSuccess;
+}
+
+void inverse_parameters(Fe<Fr> &omega, Fe<Fr> &scale, u64 n)
+{
+    Fe<Fr> oi, nfe;
+    fe_inv(oi, omega);
+    omega = oi;
+    fe_from_u32(nfe, (u32)n); // n <= 2^28
+    fe_inv(scale, nfe);
+    fe_reduce_once(scale);
+}
+
+hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omega_wire, unsigned log_n, unsigned *flag, bool inverse)
+{
+    if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
+    PANDA_TRY(order_after_null_stream(stream));
+    Fe<Fr> omega, scale;
+    fe_from_wire(omega, omega_wire);
+    if (inverse) inverse_parameters(omega, scale, (u64)1 << log_n);
+    panda::Arena &arena = panda::thread_arena();
+    PANDA_TRY(arena.reserve(4 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    unsigned passes = 0;
+    PANDA_TRY(ntt_passes(stream, arena, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes));
+    if (flag) *flag = passes & 1u;           // fft.cu:211
+    PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
+    return hipSuccess;
+}
+
+// multi-GPU step 1: local transform of the rank's decimated slab + the inter-slab twiddle w^(rank * k2)
+hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
+{
+    if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
+    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
+    PANDA_TRY(order_after_null_stream(stream));
+    const unsigned log_m = cfg.log_n - cfg.log_ranks;
+    const u64 m = (u64)1 << log_m;
+    Fe<Fr> omega, omega_m;
+    fe_from_wire(omega, (const u32 *)cfg.omega);
+    fe_pow_u64(omega_m, omega, (u64)1 << cfg.log_ranks); // root of the local size-m transforms
+    panda::Arena &arena = panda::thread_arena();
+    PANDA_TRY(arena.reserve(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    unsigned passes = 0;
+    PANDA_TRY(ntt_passes(stream, arena, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes));
+    u32 *res = (passes & 1u) ? (u32 *)cfg.d_scratch : (u32 *)cfg.d_slab;
+    if (cfg.rank != 0) {
+        u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB);
+        if (!d_ta || !d_tb) return hipErrorOutOfMemory;
+        Fe<Fr> base, base_b;
+        fe_pow_u64(base, omega, cfg.rank);
+        build_table(stream, base, nullptr, (unsigned)std::min<u64>(m, 1u << 16), d_ta);
+        if (log_m > 16) {
+            fe_pow_u64(base_b, base, (u64)1 << 16);
+            build_table(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
+        }
+        hipLaunchKernelGGL(k_slab_twiddle, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, res, d_ta, d_tb, (unsigned)m);
+        PANDA_TRY(hipGetLastError());
+    }
+    if (cfg.flag) *(unsigned *)cfg.flag = passes & 1u;
+    PANDA_TRY(hipStreamSynchronize(stream));
+    return hipSuccess;
+}
+
+// multi-GPU step 2: after the all-to-all the slab holds [j1][k2'] (G x m/G); transforms of size G down j1
+hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
+{
+    if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < 2 * cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
+    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
+    PANDA_TRY(order_after_null_stream(stream));
+    const unsigned log_m = cfg.log_n - cfg.log_ranks;
+    const u64 m = (u64)1 << log_m;
+    unsigned out_in_scratch = 0;
+    if (cfg.log_ranks != 0) {
+        Fe<Fr> omega, base;
+        fe_from_wire(omega, (const u32 *)cfg.omega);
+        panda::Arena &arena = panda::thread_arena();
+        PANDA_TRY(arena.reserve(SZ_TA + SZ_TB + SZ_PQ + 4096));
+        u32 *d_pq = (u32 *)arena.take(SZ_PQ);
+        if (!d_pq) return hipErrorOutOfMemory;
+        fe_pow_u64(base, omega, m); // w^m has order G
+        build_table(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
+        PassArgs a{};
+        a.x = (const u32 *)cfg.d_slab;
+        a.y = (u32 *)cfg.d_scratch;
+        a.pq = d_pq;
+        a.ta = a.tb = d_pq;
+        a.log_n = log_m;
+        a.lgp = 0;
+        a.la = 16;
+        a.force_tw = 0;
+        a.tile_elems = (unsigned)std::min<u64>(TILE, m);
+        a.strided_out = 1;
+        launch_pass(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
+        PANDA_TRY(hipGetLastError());
+        out_in_scratch = 1;
+    }
+    if (cfg.flag) *(unsigned *)cfg.flag = out_in_scratch;
+    PANDA_TRY(hipStreamSynchronize(stream));
+    return hipSuccess;
+}
+
+} // namespace
+
+extern "C" {
+
+panda_error panda_ntt_setup_bn254(void *input_omega)
+{
+    if (!input_omega) return panda_error_invalid_value;
+    std::lock_guard<std::mutex> lock(g_omega_mutex);
+    memcpy(g_omega_wire, input_omega, sizeof(g_omega_wire));
+    g_omega_set = true;
+    return panda_success;
+}
+
+panda_error panda_ntt_execute_bn254(panda_ntt_configuration cfg)
+{
+    u32 omega[8];
+    {
+        std::lock_guard<std::mutex> lock(g_omega_mutex);
+        if (!g_omega_set) return panda_error_invalid_value;
+        memcpy(omega, g_omega_wire, sizeof(omega));
+    }
+    return static_cast<panda_error>(ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, omega, cfg.log_n, (unsigned *)cfg.flag, false));
+}
+
+panda_error panda_ntt_execute_bn254_v1(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false));
+}
+
+panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+}
+
+panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1(cfg)); }
+
+panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2(cfg)); }
+
+panda_error panda_ntt_tear_down(void)
+{
+    std::lock_guard<std::mutex> lock(g_omega_mutex);
+    g_omega_set = false;
+    return static_cast<panda_error>(panda::release_thread_arena());
+}
+
+} // extern "C"

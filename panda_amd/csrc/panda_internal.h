@@ -1,0 +1,51 @@
+// panda_internal.h -- helpers shared by the translation units of libpanda-cuda (HIP build).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/panda_interface.h"
+
+// Early-return on a failing runtime call, printing where (the reference's HANDLE_RESULT_CUDA,
+// src/cuda/core/common/common.cuh:14-22, does the same on stdout).
+#define PANDA_TRY(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t panda_err__ = (expr);                                                                       \
+        if (panda_err__ != hipSuccess) {                                                                       \
+            printf("[panda-hip] error %d (%s) at %s:%d: %s\n", (int)panda_err__, hipGetErrorName(panda_err__), \
+                   __FILE__, __LINE__, #expr);                                                                 \
+            return panda_err__;                                                                                \
+        }                                                                                                      \
+    } while (0)
+
+namespace panda {
+
+// Grow-only device scratch arena, one per host thread and device.  The reference allocates and
+// frees seven scratch buffers per MSM call with cudaMallocAsync (msm_cuda.cuh:604-610,757-763);
+// with 288 GB of HBM it is cheaper to keep one arena alive between calls.  Released by
+// panda_msm_tear_down() / panda_ntt_tear_down().
+struct Arena {
+    void *base = nullptr;
+    size_t capacity = 0;
+    size_t used = 0;
+    int device = -1;
+
+    hipError_t reserve(size_t bytes);
+    void reset() { used = 0; }
+    void *take(size_t bytes) // 256-byte aligned carve; reserve() must have been called with the total
+    {
+        size_t off = (used + 255) & ~(size_t)255;
+        if (off + bytes > capacity) return nullptr;
+        used = off + bytes;
+        return (char *)base + off;
+    }
+    hipError_t release();
+};
+
+Arena &thread_arena();
+hipError_t release_thread_arena();
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+} // namespace panda
