@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- contract benchmark: BN254 MSM 2^24 points per GPU, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: panda_msm_execute_bn254 on this rank's
+base range (2^24 points, cached bases, Jacobian output) and, for N > 1, the all-gather of the 96-byte partials over
+RCCL plus the G - 1 point additions (weak scaling: per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+
+  value      whole-job MSM points/s = N * 2^24 * K / wall (max over ranks, barrier + synchronize on both sides)
+  roofline   the dominant kernel (k_accumulate): algorithmic bytes per launch (96 B/point) / its
+             average duration, measured with HIP events on the launch stream inside the timed region
+  cpu_baseline  the CPU oracle (port of the reference's host-debug Pippenger, c = 16, one thread) timed on a bounded
+             sample on this box's host cores; N = 1 only
+  ntt        secondary figure, outside the timed region: BN254 NTT 2^24 elements/s (forward), same box
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+BYTES_PER_POINT = 96   # 32 B scalar + 64 B affine base
+BYTES_PER_NTT_ELEM = 64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=24, help="log2 of the points per GPU (contract: 24)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=17)
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_log_n: int) -> dict:
+    """The only place bench.py touches the oracle: as the thing timed beside the GPU, never as the thing shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as po
+
+    n = 1 << sample_log_n
+    bases = po.gen_bases(po.BN254, 0xC0FFEE, n)
+    scalars = po.gen_scalars(po.F_BN254_FR, 0xC0FFEE + 1, n)
+    t = time.time()
+    po.msm(po.BN254, bases, scalars, window_bits=16, threads=1)
+    dt = time.time() - t
+    return {"value": n / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"BN254 MSM 2^{sample_log_n} random bases/scalars, oracle/msm.c (reference host-debug algorithm, 16-bit windows), "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from panda_amd import gpu_ffi as ffi
+    from panda_amd import multi_gpu
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    lib = ffi.load()
+    ffi.check(lib.panda_set_device(local_rank), "SetDeviceError")
+
+    log_n = args.log_n
+    n = 1 << log_n
+    stream = torch.cuda.Stream(device=dev)
+    pstream = ffi.PandaStream(stream.cuda_stream)
+    bases = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    result = torch.zeros(96, dtype=torch.uint8, device=dev)
+    first = rank * n  # this rank's base range of the virtual N * 2^log_n problem
+    ffi.check(lib.panda_gen_bases(0, 0x70616E6461, first, n, bases.data_ptr(), pstream), "gen_bases")
+    ffi.check(lib.panda_gen_scalars(0, 0x70616E6461 ^ 0xFFFF, first, n, scalars.data_ptr(), pstream), "gen_scalars")
+    cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), pstream, bases.data_ptr(), scalars.data_ptr(), result.data_ptr(), log_n, ffi.JACOBIAN)
+
+    phase = (C.c_float * 8)()
+    acc_ms = []
+
+    def step(timed: bool):
+        ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
+        if timed:
+            lib.panda_msm_last_phase_ms(phase)
+            acc_ms.append(list(phase))
+        if world > 1:
+            gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(gathered, result)
+            multi_gpu.combine_partials(gathered.cpu().numpy().reshape(world, 96))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.panda_stream_sync(pstream)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
+        mean = [sum(r[i] for r in acc_ms) / len(acc_ms) for i in range(8)]
+        acc_kernel_ms = mean[3]
+        achieved = BYTES_PER_POINT * n / (acc_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                if tr.get("log_n") == log_n:
+                    traffic = tr.get("k_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MSM points/s (BN254, 2^24)",
+            "value": world * n * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"BN254 MSM 2^{log_n} points per GPU, Jacobian output, bases and scalars resident in HBM",
+                       "curve": "bn254", "log_points_per_gpu": log_n, "sharding": f"base-range x{world}" if world > 1 else "none",
+                       "exchange": "all-gather of 96 B partials (RCCL) + host point additions" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * n, "kernel_ms": acc_kernel_ms},
+            "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
+        }
+        if not args.no_ntt:
+            out["ntt"] = ntt_figure(lib, ffi, torch, dev, pstream)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def ntt_figure(lib, ffi, torch, dev, pstream, log_n: int = 24, reps: int = 5) -> dict:
+    """BN254 NTT 2^24 forward, device-resident, median of `reps` (secondary headline figure)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    n = 1 << log_n
+    a = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    b = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    ffi.check(lib.panda_gen_scalars(0, 0x4E5454, 0, n, a.data_ptr(), pstream), "gen")
+    omega = _root_of_unity_host(lib, ffi, log_n)
+    flag = C.c_uint(0)
+    cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
+    times = []
+    for r in range(reps + 1):
+        t = time.perf_counter()
+        ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
+        if r:
+            times.append(time.perf_counter() - t)
+    times.sort()
+    med = times[len(times) // 2]
+    gbs = BYTES_PER_NTT_ELEM * n / med / 1e9
+    return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / med, "unit": "elements/s", "ms": med * 1e3,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
+
+
+def _root_of_unity_host(lib, ffi, log_n):
+    """omega of order 2^log_n in wire form: 7^((r-1)/2^28) squared down (bn254/paramter.cuh:241-258), computed with
+    Python integers -- no oracle involved."""
+    import numpy as np
+
+    r = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    w = pow(7, (r - 1) >> 28, r)
+    w = pow(w, 1 << (28 - log_n), r)
+    return np.frombuffer((w * (1 << 256) % r).to_bytes(32, "little"), dtype=np.uint32).copy()
+
+
+if __name__ == "__main__":
+    main()
