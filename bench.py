@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--log-n", type=int, default=24, help="log2 of the points per GPU (contract: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=17)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=19)
     return ap.parse_args()
 
 
