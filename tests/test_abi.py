@@ -1,0 +1,103 @@
+"""The C-ABI boundary without a GPU: every symbol include/panda_interface.h declares is exported by the built
+library, the by-value structs have the reference's layout, and the CPU entry points of the library
+(panda_msm_execute_*_host, panda_msm_combine_*) agree with the oracle.  No device compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as po
+from panda_amd import gpu_ffi as ffi
+from panda_amd import gpu_manager as pgm
+from panda_amd import multi_gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "panda_interface.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(panda_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_python_symbol_lists_agree():
+    assert declared_symbols() == sorted(ffi.ALL_SYMBOLS)
+    assert len(ffi.REFERENCE_SYMBOLS) == 36  # the reference defines 36
+
+
+def test_library_exports_every_declared_symbol():
+    out = subprocess.run(["nm", "-D", "--defined-only", ffi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (panda_[a-z0-9_]+)", out))
+    missing = [s for s in declared_symbols() if s not in exported]
+    assert not missing, missing
+    lib = ffi.load()
+    for s in ffi.ALL_SYMBOLS:
+        assert hasattr(lib, s)
+    assert b"gfx950" in lib.panda_version()
+
+
+def test_static_library_is_built_too():
+    a = os.path.join(os.path.dirname(ffi.LIB_PATH), "libpanda-cuda.a")
+    assert os.path.exists(a)  # `cargo:rustc-link-lib=static=panda-cuda`, build.rs:45
+
+
+def test_struct_layouts_match_reference():
+    # panda_interface.cuh:18-31,70-105 / gpu_ffi/common.rs:40-208 on LP64
+    assert C.sizeof(ffi.PandaStream) == C.sizeof(ffi.PandaEvent) == C.sizeof(ffi.PandaMemPool) == 8
+    assert C.sizeof(ffi.MSMConfiguration) == 48
+    assert [f[0] for f in ffi.MSMConfiguration._fields_] == ["mem_pool", "stream", "bases", "scalars", "results", "log_scalars_count", "msm_result_coordinate_type"]
+    assert ffi.MSMConfiguration.log_scalars_count.offset == 40 and ffi.MSMConfiguration.msm_result_coordinate_type.offset == 44
+    assert C.sizeof(ffi.NTTConfiguration) == 48 and ffi.NTTConfiguration.log_n.offset == 32 and ffi.NTTConfiguration.flag.offset == 40
+    assert C.sizeof(ffi.NttconfigurationV1) == 56 and ffi.NttconfigurationV1.omega.offset == 32 and ffi.NttconfigurationV1.flag.offset == 48
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(ffi, "_lib", None)
+    monkeypatch.setattr(ffi, "LIB_PATH", "/nonexistent/libpanda-cuda.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ffi.load()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_host_debug_entry_point(cid):
+    """panda_msm_execute_bn254_host (panda_interface.cu:162-165 -> msm_host.cuh:267-383): all-host pointers."""
+    for k, coord in ((10, pgm.JACOBIAN), (11, pgm.PROJECTIVE)):
+        n = 1 << k
+        bases = po.gen_bases(cid, 700 + k, n)
+        scalars = po.gen_scalars(po.FR_OF[cid], 800 + k, n)
+        bases[3, : po.LC_Q[cid]] = 0
+        scalars[5] = 0
+        keep = scalars.copy()
+        lib = ffi.load()
+        out = np.zeros(3 * po.LC_Q[cid], dtype=np.uint32)
+        cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), bases.ctypes.data, scalars.ctypes.data, out.ctypes.data, k, coord)
+        fn = lib.panda_msm_execute_bn254_host if cid == 0 else lib.panda_msm_execute_bls12_377_host
+        assert fn(cfg) == 0
+        got = po.hom_to_affine(cid, out) if coord == pgm.PROJECTIVE else po.to_affine(cid, out)
+        assert (got == po.msm_affine(cid, bases, scalars, window_bits=9)).all()
+        assert (scalars == keep).all()
+    assert fn(ffi.MSMConfiguration()) != 0  # null pointers are rejected with an error code, not a crash
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_combine_partials(cid):
+    n = 1 << 10
+    bases = po.gen_bases(cid, 900, n)
+    scalars = po.gen_scalars(po.FR_OF[cid], 901, n)
+    parts = []
+    for r in range(4):
+        first, cnt = multi_gpu.shard_range(n, 4, r)
+        parts.append(pgm.panda_msm_bn254_gpu_host(None, scalars[first:first + cnt], bases[first:first + cnt], curve=cid))
+    parts.append(np.zeros_like(parts[0]))  # an identity partial
+    total = multi_gpu.combine_partials(np.stack(parts), curve=cid)
+    assert (po.to_affine(cid, total.view(np.uint32)) == po.msm_affine(cid, bases, scalars, window_bits=9)).all()
+    hom = multi_gpu.combine_partials(np.stack(parts), curve=cid, coordinate_type=pgm.PROJECTIVE)
+    assert (po.hom_to_affine(cid, hom.view(np.uint32)) == po.to_affine(cid, total.view(np.uint32))).all()
+
+
+def test_gpu_manager_helpers():
+    assert pgm.log_2(1) == 0 and pgm.log_2(1024) == 10 and pgm.log_2(1500) == 10  # gpu_manager/common.rs:5-15
+    assert pgm.FIELD_ELEMENT_LEN == 32
