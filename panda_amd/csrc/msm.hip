@@ -19,9 +19,8 @@
 // Pipeline (all on cfg.stream):
 //   k_convert_bases   wire affine -> internal Montgomery radix, 64 B/point (96 B BLS12-377)
 //   k_digits          scalar -> canonical -> W signed c-bit digits (u16 codes, window-major)
-//   k_count           histogram of (window, bucket)
-//   k_scan            exclusive scan per window -> bucket offsets, cursors
-//   k_scatter         point ids (+ sign) into bucket order
+//   k_part_hist/scan/scatter  level 1 of the sort: (id, sign, lo bits) words into 2^hi partitions, LDS histograms and cursors
+//   k_bucket_sort     level 2: one workgroup per partition ranks the lo bits in LDS -> bucket offsets + point-id lists
 //   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
 //   k_fixup           merge bucket pieces that straddle chunks
 //   k_reduce_groups   4 buckets -> one weighted partial
@@ -228,61 +227,121 @@ __global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars,
     }
 }
 
-__global__ void __launch_bounds__(256) k_count(const uint16_t *__restrict__ dig, u32 *__restrict__ count, u64 total, unsigned log_n, unsigned NB)
+// ---- (window, bucket) -> point-id lists: two-level partition sort staged in LDS --------------------------------
+// Replaces the reference's three global-atomic passes (calc_lens / allo_arrs / fill_arrs, msm_cuda.cuh:159-282).
+// Bucket ids are split into `hi` (partition) and `lo` bits.  Level 1 moves every (id, sign, lo) word into its
+// partition with per-tile LDS histograms and LDS cursors; level 2 gives each partition to one workgroup, which
+// counts and ranks its `lo` values in LDS and writes the final order.  A partition's output range equals its
+// input range, so no global prefix over the 2^(c-1) buckets is needed.  No global atomics anywhere.
+constexpr unsigned SORT_TILE = 16384; // digits per workgroup in level 1
+constexpr unsigned MAX_PARTS = 1024;
+
+struct SortGeom {
+    unsigned log_n, lo_bits, H, tiles;
+};
+
+__global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ dig, u32 *__restrict__ tile_hist, SortGeom g)
 {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    u32 code = dig[e];
-    if (code == DIGIT_ZERO) return;
-    u32 w = (u32)(e >> log_n);
-    atomicAdd(&count[(u64)w * NB + (code & 0x7fffu)], 1u);
+    __shared__ u32 h[MAX_PARTS];
+    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    for (unsigned i = tid; i < g.H; i += 256) h[i] = 0;
+    __syncthreads();
+    const u64 n = (u64)1 << g.log_n;
+    const uint16_t *dw = dig + ((u64)w << g.log_n);
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    for (u64 i = begin + tid; i < end; i += 256) {
+        u32 code = dw[i];
+        if (code != DIGIT_ZERO) atomicAdd(&h[(code & 0x7fffu) >> g.lo_bits], 1u);
+    }
+    __syncthreads();
+    u32 *out = tile_hist + ((u64)w * g.tiles + tile) * g.H;
+    for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
 }
 
-// one block per window: exclusive scan of NB counts -> off[w][0..NB], cursor[w][b] = off[w][b]
-__global__ void __launch_bounds__(1024) k_scan(const u32 *__restrict__ count, u32 *__restrict__ off, u32 *__restrict__ cursor, unsigned NB)
+// one block per window: tile_hist -> exclusive prefix over tiles (in place), partition offsets part_off[w][0..H]
+__global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ tile_hist, u32 *__restrict__ part_off, SortGeom g)
 {
-    __shared__ u32 part[1024];
+    __shared__ u32 tot[MAX_PARTS];
     const unsigned w = blockIdx.x, t = threadIdx.x;
-    const unsigned per = (NB + 1023) / 1024;
-    const u32 *cw = count + (u64)w * NB;
-    u32 *ow = off + (u64)w * (NB + 1);
-    u32 *uw = cursor + (u64)w * NB;
-    u32 local = 0;
-    for (unsigned j = 0; j < per; j++) {
-        unsigned b = t * per + j;
-        if (b < NB) local += cw[b];
-    }
-    part[t] = local;
-    __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
-        u32 v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u32 run = part[t] - local;
-    for (unsigned j = 0; j < per; j++) {
-        unsigned b = t * per + j;
-        if (b < NB) {
-            ow[b] = run;
-            uw[b] = run;
-            run += cw[b];
+    u32 run = 0;
+    if (t < g.H) {
+        u32 *col = tile_hist + (u64)w * g.tiles * g.H + t;
+        for (unsigned tile = 0; tile < g.tiles; tile++) {
+            u32 v = col[(u64)tile * g.H];
+            col[(u64)tile * g.H] = run;
+            run += v;
         }
     }
-    if (t == 1023) ow[NB] = part[1023];
+    tot[t] = run;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 v = (t >= d) ? tot[t - d] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    if (t < g.H) part_off[(u64)w * (g.H + 1) + t] = tot[t] - run;
+    if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const uint16_t *__restrict__ dig, u32 *__restrict__ cursor, u32 *__restrict__ sorted, u64 total,
-                                                 unsigned log_n, unsigned NB)
+// word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n]
+__global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
+                                                      u32 *__restrict__ p1, SortGeom g)
 {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    u32 code = dig[e];
-    if (code == DIGIT_ZERO) return;
-    u32 w = (u32)(e >> log_n);
-    u32 i = (u32)(e & (((u64)1 << log_n) - 1));
-    u32 pos = atomicAdd(&cursor[(u64)w * NB + (code & 0x7fffu)], 1u);
-    sorted[((u64)w << log_n) + pos] = i | ((code & 0x8000u) << 16);
+    __shared__ u32 cur[MAX_PARTS];
+    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
+    const u32 *po = part_off + (u64)w * (g.H + 1);
+    for (unsigned i = tid; i < g.H; i += 256) cur[i] = po[i] + base[i];
+    __syncthreads();
+    const u64 n = (u64)1 << g.log_n;
+    const uint16_t *dw = dig + ((u64)w << g.log_n);
+    u32 *pw = p1 + ((u64)w << g.log_n);
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    const u32 lo_mask = (1u << g.lo_bits) - 1;
+    for (u64 i = begin + tid; i < end; i += 256) {
+        u32 code = dw[i];
+        if (code == DIGIT_ZERO) continue;
+        u32 b = code & 0x7fffu;
+        u32 pos = atomicAdd(&cur[b >> g.lo_bits], 1u);
+        pw[pos] = ((b & lo_mask) << (g.log_n + 1)) | ((code >> 15) << g.log_n) | (u32)i;
+    }
+}
+
+// one workgroup per (partition, window): count the lo values, publish the bucket offsets, rank and write the ids
+__global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
+                                                     u32 *__restrict__ sorted, SortGeom g, unsigned NB)
+{
+    __shared__ u32 cnt[128], cur[128];
+    const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+    const unsigned L = 1u << g.lo_bits;
+    const u32 ps = part_off[(u64)w * (g.H + 1) + h], pe = part_off[(u64)w * (g.H + 1) + h + 1];
+    const u32 *pw = p1 + ((u64)w << g.log_n);
+    u32 *sw = sorted + ((u64)w << g.log_n);
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    for (u32 j = ps + tid; j < pe; j += 256) atomicAdd(&cnt[pw[j] >> (g.log_n + 1)], 1u);
+    __syncthreads();
+    u32 mine = tid < 128 ? cnt[tid] : 0;
+    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
+        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
+        __syncthreads();
+        if (tid < 128) cnt[tid] += v;
+        __syncthreads();
+    }
+    if (tid < L) {
+        u32 start = ps + cnt[tid] - mine;
+        cur[tid] = start;
+        off[(u64)w * (NB + 1) + ((u64)h << g.lo_bits) + tid] = start;
+    }
+    if (h == g.H - 1 && tid == 0) off[(u64)w * (NB + 1) + NB] = pe;
+    __syncthreads();
+    const u32 id_mask = (1u << g.log_n) - 1;
+    for (u32 j = ps + tid; j < pe; j += 256) {
+        u32 v = pw[j];
+        u32 pos = atomicAdd(&cur[v >> (g.log_n + 1)], 1u);
+        sw[pos] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
+    }
 }
 
 // first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
@@ -472,7 +531,7 @@ __global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in,
 thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 unsigned g_window_override = 0;
 
-const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "count+scan", "scatter", "accumulate",
+const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
 
 // window width policy (replaces get_window_bits_count, msm_cuda.cuh:21-45)
@@ -521,7 +580,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     // ---- scratch
     const size_t sz_bases = panda::align256(n * 2 * LQ * 4);
     const size_t sz_dig = panda::align256(n * W * 2);
-    const size_t sz_count = panda::align256((size_t)W * NB * 4);
+    SortGeom geom;
+    geom.log_n = log_n;
+    geom.lo_bits = std::min(std::min(7u, c - 1), 31u - log_n);
+    geom.H = 1u << (c - 1 - geom.lo_bits);
+    geom.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
+    const size_t sz_thist = panda::align256((size_t)W * geom.tiles * geom.H * 4);
+    const size_t sz_poff = panda::align256((size_t)W * (geom.H + 1) * 4);
     const size_t sz_off = panda::align256((size_t)W * (NB + 1) * 4);
     const size_t sz_sorted = panda::align256(n * W * 4);
     const size_t sz_bacc = panda::align256((size_t)W * NB * PW * 4);
@@ -530,11 +596,12 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const size_t sz_l1 = panda::align256((size_t)W * lvl1 * PW * 4);
     const size_t sz_win = panda::align256((size_t)W * PW * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_dig + 2 * sz_count + sz_off + sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + 4096));
+    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + 4096));
     u32 *d_bases = (u32 *)arena.take(sz_bases);
     uint16_t *d_dig = (uint16_t *)arena.take(sz_dig);
-    u32 *d_count = (u32 *)arena.take(sz_count);
-    u32 *d_cursor = (u32 *)arena.take(sz_count);
+    u32 *d_thist = (u32 *)arena.take(sz_thist);
+    u32 *d_poff = (u32 *)arena.take(sz_poff);
+    u32 *d_p1 = (u32 *)arena.take(sz_sorted);
     u32 *d_off = (u32 *)arena.take(sz_off);
     u32 *d_sorted = (u32 *)arena.take(sz_sorted);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
@@ -550,16 +617,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
 
     PANDA_TRY(mark(0));
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
-    const u64 total = n * W;
-    const unsigned blocks_total = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
     hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, c, W);
     PANDA_TRY(mark(1));
-    PANDA_TRY(hipMemsetAsync(d_count, 0, sz_count, stream));
-    hipLaunchKernelGGL(k_count, dim3(blocks_total), dim3(256), 0, stream, d_dig, d_count, total, log_n, NB);
-    hipLaunchKernelGGL(k_scan, dim3(W), dim3(1024), 0, stream, d_count, d_off, d_cursor, NB);
+    hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
+    hipLaunchKernelGGL(k_part_scan, dim3(W), dim3(1024), 0, stream, d_thist, d_poff, geom);
+    hipLaunchKernelGGL(k_part_scatter, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
     PANDA_TRY(mark(2));
-    hipLaunchKernelGGL(k_scatter, dim3(blocks_total), dim3(256), 0, stream, d_dig, d_cursor, d_sorted, total, log_n, NB);
+    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(256), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
     PANDA_TRY(mark(3));
     PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, W), dim3(128), 0, stream, d_bases, d_sorted, d_off, d_bacc, d_parts, log_n, NB, K,

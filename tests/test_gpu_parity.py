@@ -341,3 +341,36 @@ def test_ntt_2_24_roundtrip_and_spot_check(gm):
     d_a.free()
     d_b.free()
     del c
+
+
+@pytest.mark.parametrize("log_ranks,log_n", [(1, 6), (2, 12), (3, 15)])
+def test_ntt_slab_steps_single_gpu(gm, log_ranks, log_n):
+    """The two device halves of the sharded NTT (panda_ntt_slab_step{1,2}_bn254), with the all-to-all done on the host:
+    every rank's slab goes through the same GPU one after the other; the assembled output must be the plain NTT."""
+    from panda_amd import multi_gpu
+    fid = po.F_BN254_FR
+    G, n = 1 << log_ranks, 1 << log_n
+    m = n // G
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 0x51AB, n)
+    lib = ffi.load()
+    after1 = []
+    for r in range(G):
+        d_slab, d_scr = DeviceBuffer.from_host(multi_gpu.slab_of(x, G, r)), DeviceBuffer(m * 32)
+        flag = C.c_uint(7)
+        cfg = ffi.NttSlabConfiguration(gm.exec_stream.raw, d_slab.ptr, d_scr.ptr, C.c_void_p(om.ctypes.data), log_n, log_ranks, r, C.pointer(flag))
+        ffi.check(lib.panda_ntt_slab_step1_bn254(cfg), "step1")
+        after1.append((d_scr if flag.value else d_slab).to_host().reshape(m, 8))
+        d_slab.free()
+        d_scr.free()
+    outs = []
+    for q in range(G):
+        recv = np.concatenate([after1[j1][q * (m // G):(q + 1) * (m // G)] for j1 in range(G)])  # what all_to_all_single delivers
+        d_slab, d_scr = DeviceBuffer.from_host(recv), DeviceBuffer(m * 32)
+        flag = C.c_uint(7)
+        cfg = ffi.NttSlabConfiguration(gm.exec_stream.raw, d_slab.ptr, d_scr.ptr, C.c_void_p(om.ctypes.data), log_n, log_ranks, q, C.pointer(flag))
+        ffi.check(lib.panda_ntt_slab_step2_bn254(cfg), "step2")
+        outs.append((d_scr if flag.value else d_slab).to_host().reshape(m, 8))
+        d_slab.free()
+        d_scr.free()
+    assert (multi_gpu.natural_from_slab_outputs(outs) == po.ntt(fid, x, om, log_n)).all()
