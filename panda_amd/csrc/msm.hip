@@ -194,8 +194,17 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ w
 
 // scalar (Montgomery wire form) -> W signed digits.  code = (neg << 15) | (|d| - 1), DIGIT_ZERO for d = 0.
 // Replaces init_handle_scalars_kernel + the slice extraction of calc_lens/fill_arrs (msm_cuda.cuh:148-205,232-282).
+// Window layout: BITS+1 scalar bits (one spare for the signed-digit carry) cut into W windows whose widths differ by
+// at most one, so that the top window is as wide as the others (a narrow top window would put all n points into a
+// handful of buckets).  width[k] <= 16.
+struct WindowPlan {
+    unsigned W;
+    unsigned char width[40];
+    unsigned short lo[40];
+};
+
 template <class Fr>
-__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ dig, u64 n, unsigned c, unsigned W)
+__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ dig, u64 n, WindowPlan plan)
 {
     constexpr int L = Fr::L;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,10 +213,11 @@ __global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars,
     load_words<L>(w, scalars + i * L);
     fe_wire_to_canonical<Fr>(s, w);
     s[L] = 0;
-    const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
     u32 carry = 0;
-    for (unsigned k = 0; k < W; k++) {
-        unsigned lo = k * c, m = lo >> 5, sh = lo & 31;
+    for (unsigned k = 0; k < plan.W; k++) {
+        const unsigned c = plan.width[k];
+        const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+        unsigned lo = plan.lo[k], m = lo >> 5, sh = lo & 31;
         u32 raw = 0;
         if (m < (unsigned)L) {
             u64 v = s[m] | ((u64)s[m + 1] << 32);
@@ -430,9 +440,14 @@ __global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ base
 // bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
 // also is t0's first run and started earlier -- impossible here since t0 = start / K), the ONLY run of every
 // chunk strictly between (slot 0) and the FIRST run of t1 (slot 0).
+// Buckets cut into more than LONG_SPAN pieces (heavily skewed scalars) are queued for k_fixup_long instead of being
+// summed by one thread.
+constexpr unsigned LONG_SPAN = 16;
+constexpr unsigned LONG_BLOCKS = 64; // workgroups per window that serve the queue
+
 template <class F>
 __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB,
-                                               unsigned K, unsigned chunks)
+                                               unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
@@ -443,6 +458,16 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
     if (s == e) return; // empty: bucket_acc was zeroed (identity)
     const u32 t0 = s / K, t1 = (e - 1) / K;
     if (t0 == t1) return; // lies inside one chunk: written by k_accumulate
+    if (t1 - t0 > LONG_SPAN) {
+        u32 slot = atomicAdd(&long_count[w], 1u); // a handful per window at most: (t1 - t0) > LONG_SPAN bounds it by chunks / LONG_SPAN
+        if (slot < long_cap) {
+            u32 *e3 = long_list + ((u64)w * long_cap + slot) * 3;
+            e3[0] = b;
+            e3[1] = t0;
+            e3[2] = t1;
+        }
+        return;
+    }
     const u32 *pw = parts + (u64)w * chunks * 2 * PW;
     Xyzz<F> acc, q;
     load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
@@ -451,6 +476,40 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
         xyzz_add(acc, q);
     }
     store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+}
+
+// one workgroup per queued bucket: 256 threads stride over its pieces, then an LDS tree
+template <class F>
+__global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB, unsigned chunks,
+                                                    const u32 *__restrict__ long_count, const u32 *__restrict__ long_list, unsigned long_cap)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
+    const unsigned w = blockIdx.y, t = threadIdx.x;
+    const u32 count = min(long_count[w], long_cap);
+    const u32 *pw = parts + (u64)w * chunks * 2 * PW;
+    for (u32 item = blockIdx.x; item < count; item += gridDim.x) { // count is uniform over the block: barriers below are safe
+        const u32 *e3 = long_list + ((u64)w * long_cap + item) * 3;
+        const u32 b = e3[0], t0 = e3[1], t1 = e3[2];
+        Xyzz<F> acc, q;
+        xyzz_set_identity(acc);
+        for (u32 c = t0 + t; c <= t1; c += 256) {
+            load_xyzz<F>(q, pw + ((u64)c * 2 + (c == t0 ? 1 : 0)) * PW);
+            xyzz_add(acc, q);
+        }
+        store_xyzz<F>(lds + t * PW, acc);
+        __syncthreads();
+        for (unsigned s = 128; s > 0; s >>= 1) {
+            if (t < s) {
+                load_xyzz<F>(q, lds + (t + s) * PW);
+                xyzz_add(acc, q);
+                store_xyzz<F>(lds + t * PW, acc);
+            }
+            __syncthreads();
+        }
+        if (t == 0) store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+        __syncthreads();
+    }
 }
 
 // k * p for a small scalar k (double-and-add from the top bit)
@@ -542,13 +601,27 @@ unsigned pick_window_bits(unsigned log_n)
     return (unsigned)std::min(std::max(c, 4), 16);
 }
 
+WindowPlan make_plan(unsigned total_bits, unsigned c)
+{
+    WindowPlan p{};
+    p.W = (total_bits + c - 1) / c;
+    const unsigned base = total_bits / p.W, rem = total_bits % p.W;
+    unsigned lo = 0;
+    for (unsigned k = 0; k < p.W; k++) {
+        p.width[k] = (unsigned char)(base + (k < rem ? 1 : 0));
+        p.lo[k] = (unsigned short)lo;
+        lo += p.width[k];
+    }
+    return p;
+}
+
 template <class F>
-void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, unsigned c)
+void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, const WindowPlan &plan)
 {
     Xyzz<F> acc, d;
     xyzz_set_identity(acc);
     for (int w = (int)windows.size() - 1; w >= 0; w--) {
-        for (unsigned k = 0; k < c; k++) {
+        for (unsigned k = 0; k < plan.width[w]; k++) {
             xyzz_dbl(d, acc);
             acc = d;
         }
@@ -568,8 +641,19 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const unsigned log_n = cfg.log_scalars_count;
     if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
-    const unsigned c = pick_window_bits(log_n);
-    const unsigned W = (Fr::BITS + 1 + c - 1) / c; // one spare bit for the signed-digit carry
+    // BITS + 1: one spare bit for the signed-digit carry.  The top window must never carry out: its largest raw value
+    // (top bits of r - 1, plus a carry in) has to stay below half its range; widen the plan by a bit until it does.
+    WindowPlan plan{};
+    for (unsigned total = Fr::BITS + 1;; total++) {
+        plan = make_plan(total, pick_window_bits(log_n));
+        const unsigned lo = plan.lo[plan.W - 1], m = lo >> 5, sh = lo & 31;
+        u64 top = m < (unsigned)LR ? ((u64)Fr::PW[m] >> sh) : 0;
+        if (m + 1 < (unsigned)LR) top |= (u64)Fr::PW[m + 1] << (32 - sh);
+        if (m + 2 < (unsigned)LR && sh) top |= (u64)Fr::PW[m + 2] << (64 - sh);
+        if (top + 1 < ((u64)1 << (plan.width[plan.W - 1] - 1)) || total > Fr::BITS + 8) break;
+    }
+    const unsigned W = plan.W;
+    const unsigned c = plan.width[0]; // widest window
     const unsigned NB = 1u << (c - 1);
     const unsigned K = log_n >= 22 ? 64 : (log_n >= 16 ? 32 : 16);
     const unsigned chunks = (unsigned)((n + K - 1) / K);
@@ -595,8 +679,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const size_t sz_gsum = panda::align256((size_t)W * groups * PW * 4);
     const size_t sz_l1 = panda::align256((size_t)W * lvl1 * PW * 4);
     const size_t sz_win = panda::align256((size_t)W * PW * 4);
+    const unsigned long_cap = chunks / LONG_SPAN + 2;
+    const size_t sz_lcount = panda::align256((size_t)W * 4);
+    const size_t sz_llist = panda::align256((size_t)W * long_cap * 3 * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + 4096));
+    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 4096));
     u32 *d_bases = (u32 *)arena.take(sz_bases);
     uint16_t *d_dig = (uint16_t *)arena.take(sz_dig);
     u32 *d_thist = (u32 *)arena.take(sz_thist);
@@ -609,7 +696,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     u32 *d_gsum = (u32 *)arena.take(sz_gsum);
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_win = (u32 *)arena.take(sz_win);
-    if (!d_win) return hipErrorOutOfMemory;
+    u32 *d_lcount = (u32 *)arena.take(sz_lcount);
+    u32 *d_llist = (u32 *)arena.take(sz_llist);
+    if (!d_win || !d_llist) return hipErrorOutOfMemory;
 
     hipEvent_t ev[8];
     for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
@@ -618,7 +707,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     PANDA_TRY(mark(0));
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
-    hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, c, W);
+    hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, plan);
     PANDA_TRY(mark(1));
     hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
     hipLaunchKernelGGL(k_part_scan, dim3(W), dim3(1024), 0, stream, d_thist, d_poff, geom);
@@ -630,7 +719,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, W), dim3(128), 0, stream, d_bases, d_sorted, d_off, d_bacc, d_parts, log_n, NB, K,
                        chunks);
     PANDA_TRY(mark(4));
-    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, W), dim3(128), 0, stream, d_off, d_parts, d_bacc, NB, K, chunks);
+    PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
+    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, W), dim3(128), 0, stream, d_off, d_parts, d_bacc, NB, K, chunks, d_lcount, d_llist, long_cap);
+    hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, W), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
     PANDA_TRY(mark(5));
     hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, W), dim3(128), 0, stream, d_bacc, d_gsum, NB, groups);
     hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(lvl1, W), dim3(256), 0, stream, d_gsum, d_l1, groups, per1);
@@ -653,7 +744,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
         }
     }
     Xyzz<Fq> result;
-    host_horner(result, windows, c);
+    host_horner(result, windows, plan);
     u32 out[3 * LQ];
     if (cfg.msm_result_coordinate_type == PROJECTIVE)
         xyzz_to_homogeneous_wire(out, result);
