@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ w
 // handful of buckets).  width[k] <= 16.
 struct WindowPlan {
     unsigned W;
-    unsigned char width[40];
-    unsigned short lo[40];
+    unsigned char width[64];
+    unsigned short lo[64];
 };
 
 template <class Fr>
@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ base
 // chunk strictly between (slot 0) and the FIRST run of t1 (slot 0).
 // Buckets cut into more than LONG_SPAN pieces (heavily skewed scalars) are queued for k_fixup_long instead of being
 // summed by one thread.
-constexpr unsigned LONG_SPAN = 16;
-constexpr unsigned LONG_BLOCKS = 64; // workgroups per window that serve the queue
+constexpr unsigned LONG_SPAN = 128;
+constexpr unsigned LONG_BLOCKS = 256; // workgroups per window that serve the queue
 
 template <class F>
 __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB,
