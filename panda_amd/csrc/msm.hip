@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars,
 // partition with per-tile LDS histograms and LDS cursors; level 2 gives each partition to one workgroup, which
 // counts and ranks its `lo` values in LDS and writes the final order.  A partition's output range equals its
 // input range, so no global prefix over the 2^(c-1) buckets is needed.  No global atomics anywhere.
-constexpr unsigned SORT_TILE = 16384; // digits per workgroup in level 1
+constexpr unsigned SORT_TILE = 8192; // digits per workgroup in level 1
 constexpr unsigned MAX_PARTS = 1024;
 
 struct SortGeom {
@@ -294,15 +294,56 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ tile_hist,
     if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
 }
 
-// word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n]
+// block-wide exclusive scan of `count` (<= 1024) LDS words in place, 256 threads; returns nothing, callers re-sync
+__device__ __forceinline__ void block_exclusive_scan_256(u32 *a, unsigned count, u32 *scratch /* 256 words */)
+{
+    const unsigned tid = threadIdx.x;
+    const unsigned per = (count + 255) / 256;
+    u32 local = 0;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned i = tid * per + j;
+        if (i < count) local += a[i];
+    }
+    scratch[tid] = local;
+    __syncthreads();
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        u32 v = (tid >= d) ? scratch[tid - d] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    u32 run = scratch[tid] - local;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned i = tid * per + j;
+        if (i < count) {
+            u32 v = a[i];
+            a[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+}
+
+// word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n].
+// The tile is first grouped by partition in LDS (local counting sort), then written out linearly, so that a wave
+// stores runs of consecutive addresses instead of 64 unrelated 4-byte words.
 __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
                                                       u32 *__restrict__ p1, SortGeom g)
 {
-    __shared__ u32 cur[MAX_PARTS];
+    __shared__ u32 lstart[MAX_PARTS]; // local start of each partition's run in the staging buffer
+    __shared__ u32 lcur[MAX_PARTS];   // local cursor
+    __shared__ u32 gbase[MAX_PARTS];  // global position of this tile's first element of the partition
+    __shared__ u32 words[SORT_TILE];
+    __shared__ uint16_t parts_of[SORT_TILE];
+    __shared__ u32 scratch[256];
     const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
     const u32 *po = part_off + (u64)w * (g.H + 1);
-    for (unsigned i = tid; i < g.H; i += 256) cur[i] = po[i] + base[i];
+    for (unsigned i = tid; i < g.H; i += 256) {
+        lstart[i] = 0;
+        lcur[i] = 0;
+        gbase[i] = po[i] + base[i];
+    }
     __syncthreads();
     const u64 n = (u64)1 << g.log_n;
     const uint16_t *dw = dig + ((u64)w << g.log_n);
@@ -311,26 +352,45 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict
     const u32 lo_mask = (1u << g.lo_bits) - 1;
     for (u64 i = begin + tid; i < end; i += 256) {
         u32 code = dw[i];
+        if (code != DIGIT_ZERO) atomicAdd(&lstart[(code & 0x7fffu) >> g.lo_bits], 1u);
+    }
+    __syncthreads();
+    block_exclusive_scan_256(lstart, g.H, scratch);
+    for (u64 i = begin + tid; i < end; i += 256) {
+        u32 code = dw[i];
         if (code == DIGIT_ZERO) continue;
-        u32 b = code & 0x7fffu;
-        u32 pos = atomicAdd(&cur[b >> g.lo_bits], 1u);
-        pw[pos] = ((b & lo_mask) << (g.log_n + 1)) | ((code >> 15) << g.log_n) | (u32)i;
+        u32 b = code & 0x7fffu, h = b >> g.lo_bits;
+        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
+        words[slot] = ((b & lo_mask) << (g.log_n + 1)) | ((code >> 15) << g.log_n) | (u32)i;
+        parts_of[slot] = (uint16_t)h;
+    }
+    __syncthreads();
+    const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
+    for (u32 j = tid; j < total; j += 256) {
+        u32 h = parts_of[j];
+        pw[gbase[h] + (j - lstart[h])] = words[j];
     }
 }
 
-// one workgroup per (partition, window): count the lo values, publish the bucket offsets, rank and write the ids
+// one workgroup per (partition, window): count the lo values, publish the bucket offsets, then rank the ids chunk by
+// chunk in LDS and write each chunk out as runs
+constexpr unsigned BS_CHUNK = 8192;
+
 __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
                                                      u32 *__restrict__ sorted, SortGeom g, unsigned NB)
 {
-    __shared__ u32 cnt[128], cur[128];
+    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
+    __shared__ u32 words[BS_CHUNK];
+    __shared__ unsigned char lo_of[BS_CHUNK];
     const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
     const unsigned L = 1u << g.lo_bits;
     const u32 ps = part_off[(u64)w * (g.H + 1) + h], pe = part_off[(u64)w * (g.H + 1) + h + 1];
     const u32 *pw = p1 + ((u64)w << g.log_n);
     u32 *sw = sorted + ((u64)w << g.log_n);
+    const unsigned shift = g.log_n + 1;
     if (tid < 128) cnt[tid] = 0;
     __syncthreads();
-    for (u32 j = ps + tid; j < pe; j += 256) atomicAdd(&cnt[pw[j] >> (g.log_n + 1)], 1u);
+    for (u32 j = ps + tid; j < pe; j += 256) atomicAdd(&cnt[pw[j] >> shift], 1u);
     __syncthreads();
     u32 mine = tid < 128 ? cnt[tid] : 0;
     for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
@@ -347,10 +407,42 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1,
     if (h == g.H - 1 && tid == 0) off[(u64)w * (NB + 1) + NB] = pe;
     __syncthreads();
     const u32 id_mask = (1u << g.log_n) - 1;
-    for (u32 j = ps + tid; j < pe; j += 256) {
-        u32 v = pw[j];
-        u32 pos = atomicAdd(&cur[v >> (g.log_n + 1)], 1u);
-        sw[pos] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
+    for (u32 cbeg = ps; cbeg < pe; cbeg += BS_CHUNK) { // pe, ps are uniform over the block: barriers are safe
+        const u32 cend = min(cbeg + BS_CHUNK, pe);
+        if (tid < 128) {
+            lstart[tid] = 0;
+            lcur[tid] = 0;
+        }
+        __syncthreads();
+        for (u32 j = cbeg + tid; j < cend; j += 256) atomicAdd(&lstart[pw[j] >> shift], 1u);
+        __syncthreads();
+        u32 c0 = tid < 128 ? lstart[tid] : 0;
+        for (unsigned d = 1; d < 128; d <<= 1) {
+            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
+            __syncthreads();
+            if (tid < 128) lstart[tid] += v;
+            __syncthreads();
+        }
+        if (tid < 128) {
+            lstart[tid] -= c0; // exclusive
+            cnt[tid] = c0;
+        }
+        __syncthreads();
+        for (u32 j = cbeg + tid; j < cend; j += 256) {
+            u32 v = pw[j];
+            u32 l = v >> shift;
+            u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
+            words[slot] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
+            lo_of[slot] = (unsigned char)l;
+        }
+        __syncthreads();
+        for (u32 j = tid; j < cend - cbeg; j += 256) {
+            u32 l = lo_of[j];
+            sw[cur[l] + (j - lstart[l])] = words[j];
+        }
+        __syncthreads();
+        if (tid < 128) cur[tid] += cnt[tid];
+        __syncthreads();
     }
 }
 
