@@ -1,0 +1,293 @@
+// gpu_manager.cpp -- see gpu_manager.hpp.  Plain C++ over the C ABI: no HIP headers needed here.
+#include "gpu_manager.hpp"
+
+#include <cassert>
+
+namespace panda_host {
+
+namespace {
+struct Event { // PandaEvent::new / record / sync (gpu_ffi/common.rs:95-132); destroyed at scope end
+    panda_event ev{};
+    bool ok = false;
+    Event() { ok = panda_event_create(&ev, true, true) == 0; }
+    ~Event()
+    {
+        if (ok) panda_event_destroy(ev);
+    }
+};
+
+PandaGpuError stream_new(panda_stream *s) { return panda_stream_create(s, true) == 0 ? PandaGpuError::Ok : PandaGpuError::StremCreateErr; } // common.rs:47-54
+} // namespace
+
+PandaGpuError get_device_number(int *count)
+{
+    *count = 0;
+    return panda_get_device_number(count) == 0 ? PandaGpuError::Ok : PandaGpuError::GetDeviceCountError;
+}
+
+PandaGpuError set_device(size_t device_id) { return panda_set_device((int)device_id) == 0 ? PandaGpuError::Ok : PandaGpuError::SetDeviceError; }
+
+PandaGpuError device_info(int device_id, PandaDeviceInfo *out)
+{
+    if (panda_set_device(device_id) != 0) return PandaGpuError::SetDeviceError;
+    size_t f = 0, t = 0;
+    if (panda_mem_get_info(&f, &t) != 0) return PandaGpuError::DeviceGetDeviceMemoryInfoError;
+    out->free = f;
+    out->total = t;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::init_hardware(size_t device_id, panda_mem_pool *pool)
+{
+    (void)set_device(device_id); // the reference ignores this result too (wrapper.rs:116)
+    return panda_mem_pool_create(pool, (int)device_id) == 0 ? PandaGpuError::Ok : PandaGpuError::MemPoolCreateErr;
+}
+
+PandaGpuError PandaGpuManager::create(size_t device_id, PandaGpuManager *out)
+{
+    int n = 0;
+    PandaGpuError e = get_device_number(&n);
+    if (e != PandaGpuError::Ok) return e;
+    if (n == 0) return PandaGpuError::GetDeviceCountError;
+    PandaGpuManager gm;
+    gm.device_id_ = device_id;
+    if ((e = init_hardware(device_id, &gm.mem_pool_)) != PandaGpuError::Ok) return e;
+    for (panda_stream *s : {&gm.default_stream_, &gm.h2d_stream_, &gm.d2h_stream_, &gm.exec_stream_})
+        if ((e = stream_new(s)) != PandaGpuError::Ok) return e;
+    *out = gm;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::init_msm_cached_bases(Bytes bases, void **d_ptr)
+{
+    *d_ptr = nullptr;
+    if (panda_malloc(d_ptr, bases.len) != 0) return PandaGpuError::CreateContextError;
+    if (panda_memcpy(*d_ptr, bases.data, bases.len) != 0) return PandaGpuError::CreateContextError;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::init_msm_cached_scalars(Bytes scalars, void **d_ptr) { return init_msm_cached_bases(scalars, d_ptr); }
+
+PandaGpuError PandaGpuManager::init_msm(const std::vector<Bytes> &bases, std::vector<void *> *d_ptrs)
+{
+    d_ptrs->clear();
+    for (const Bytes &b : bases) {
+        void *d = nullptr;
+        PandaGpuError e = init_msm_cached_bases(b, &d);
+        if (e != PandaGpuError::Ok) return e;
+        d_ptrs->push_back(d);
+    }
+    return panda_msm_setup_bn254() == 0 ? PandaGpuError::Ok : PandaGpuError::CreateContextError;
+}
+
+PandaGpuError PandaGpuManager::init_ntt(Bytes omega)
+{
+    return panda_ntt_setup_bn254(const_cast<uint8_t *>(omega.data)) == 0 ? PandaGpuError::Ok : PandaGpuError::CreateContextError;
+}
+
+PandaGpuError PandaGpuManager::init_all(size_t device_id, PandaGpuManagerInitUnitType type, const std::vector<Bytes> *bases, const Bytes *omega,
+                                        PandaGpuManager *out)
+{
+    if (type == PandaGpuManagerInitUnitType::None) return PandaGpuError::MSMBasesAddrError;
+    const bool want_msm = type == PandaGpuManagerInitUnitType::MSM || type == PandaGpuManagerInitUnitType::ALL;
+    const bool want_ntt = type == PandaGpuManagerInitUnitType::NTT || type == PandaGpuManagerInitUnitType::ALL;
+    if (want_msm && !bases) return PandaGpuError::MSMBasesAddrError;
+    if (want_ntt && !omega) return PandaGpuError::NTTOmegaAddrError;
+    PandaGpuManager gm;
+    PandaGpuError e = create(device_id, &gm);
+    if (e != PandaGpuError::Ok) return e;
+    if (want_msm && (e = init_msm(*bases, &gm.d_bases)) != PandaGpuError::Ok) return e;
+    if (want_ntt) (void)init_ntt(*omega); // result ignored as in the reference (wrapper.rs:81,95)
+    *out = gm;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::wait_h2d() const
+{
+    Event ev;
+    if (!ev.ok) return PandaGpuError::EventCreateErr;
+    if (panda_event_record(ev.ev, h2d_stream_) != 0) return PandaGpuError::EventRecordErr;
+    if (panda_stream_wait_event(exec_stream_, ev.ev) != 0) return PandaGpuError::StreamWaitEventErr;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::wait_exec() const
+{
+    Event ev;
+    if (!ev.ok) return PandaGpuError::EventCreateErr;
+    if (panda_event_record(ev.ev, exec_stream_) != 0) return PandaGpuError::EventRecordErr;
+    if (panda_stream_wait_event(d2h_stream_, ev.ev) != 0) return PandaGpuError::StreamWaitEventErr;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::sync() const
+{
+    for (panda_stream s : {h2d_stream_, exec_stream_, d2h_stream_})
+        if (panda_stream_synchronize(s) != 0) return PandaGpuError::StreamSyncErr;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError PandaGpuManager::deinit()
+{
+    for (void *p : d_bases)
+        if (panda_free(p) != 0) return PandaGpuError::DestroyContextErr;
+    for (void *p : d_scalars)
+        if (panda_free(p) != 0) return PandaGpuError::DestroyContextErr;
+    d_bases.clear();
+    d_scalars.clear();
+    scalars_len.clear();
+    if (panda_msm_tear_down() != 0) return PandaGpuError::DestroyContextErr;
+    if (panda_mem_pool_destroy(mem_pool_) != 0) return PandaGpuError::DestroyContextErr;
+    for (panda_stream s : {default_stream_, h2d_stream_, d2h_stream_, exec_stream_})
+        if (panda_stream_destroy(s) != 0) return PandaGpuError::StreamDestroyErr;
+    return PandaGpuError::Ok;
+}
+
+PandaGpuError malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool pool, panda_stream stream)
+{
+    return panda_malloc_from_pool_async(ptr, size, pool, stream) == 0 ? PandaGpuError::Ok : PandaGpuError::AsyncPoolMallocErr;
+}
+
+PandaGpuError memcpy_async(void *dst, const void *src, size_t size, panda_stream stream)
+{
+    return panda_memcpy_async(dst, src, size, stream) == 0 ? PandaGpuError::Ok : PandaGpuError::AsyncMemcopyErr;
+}
+
+PandaGpuError free_async(void *ptr, panda_stream stream) { return panda_free_async(ptr, stream) == 0 ? PandaGpuError::Ok : PandaGpuError::AsyncMemcopyErr; }
+
+PandaGpuError memory_alloc_and_copy(const PandaGpuManager &gm, Bytes h, panda_stream stream, void **d_values)
+{
+    PandaGpuError e = malloc_from_pool_async(d_values, h.len, gm.get_mem_pool(), stream);
+    if (e != PandaGpuError::Ok) return e;
+    return memcpy_async(*d_values, h.data, h.len, stream);
+}
+
+namespace {
+
+// the common tail of the four device MSM entry points: result buffer, configuration, execute, D2H, frees
+PandaGpuError run_msm(const PandaGpuManager &gm, void *d_scalars, void *d_bases, uint32_t log_n, bool free_scalars, bool free_bases,
+                      std::vector<uint8_t> *result)
+{
+    const size_t result_buf_len = FIELD_ELEMENT_LEN * 3;
+    void *d_result = nullptr;
+    PandaGpuError e = malloc_from_pool_async(&d_result, result_buf_len, gm.get_mem_pool(), gm.get_h2d_stream());
+    if (e != PandaGpuError::Ok) return e;
+    if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+    panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_bases, d_scalars, d_result, log_n, gm.get_msm_result_coordinate_type()};
+    if (panda_msm_execute_bn254(cfg) != 0) return PandaGpuError::SchedulingErr;
+    {
+        Event done;
+        if (!done.ok) return PandaGpuError::EventCreateErr;
+        if (panda_event_record(done.ev, gm.get_exec_stream()) != 0) return PandaGpuError::EventRecordErr;
+        (void)panda_event_sync(done.ev);
+    }
+    void *host = nullptr;
+    if (panda_malloc_host(&host, result_buf_len) != 0) return PandaGpuError::CreateContextError;
+    const bool copied = panda_memcpy(host, d_result, result_buf_len) == 0;
+    if (copied) result->assign((uint8_t *)host, (uint8_t *)host + result_buf_len);
+    panda_free_host(host);
+    if (!copied) return PandaGpuError::CreateContextError;
+    if (free_scalars && panda_free(d_scalars) != 0) return PandaGpuError::CreateContextError;
+    if (free_bases && panda_free(d_bases) != 0) return PandaGpuError::CreateContextError;
+    if (panda_free(d_result) != 0) return PandaGpuError::CreateContextError;
+    return PandaGpuError::Ok;
+}
+
+} // namespace
+
+PandaGpuError panda_msm_bn254_gpu(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result)
+{
+    void *d_scalars = nullptr, *d_bases = nullptr;
+    PandaGpuError e = memory_alloc_and_copy(gm, scalars, gm.get_h2d_stream(), &d_scalars);
+    if (e != PandaGpuError::Ok) return e;
+    if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+    if ((e = memory_alloc_and_copy(gm, bases, gm.get_h2d_stream(), &d_bases)) != PandaGpuError::Ok) return e;
+    if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+    return run_msm(gm, d_scalars, d_bases, log_2(scalars.len / FIELD_ELEMENT_LEN), true, true, result);
+}
+
+PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, Bytes scalars, size_t bases_index, std::vector<uint8_t> *result)
+{
+    void *d_bases = gm.get_params_bases_ptr_mut(bases_index);
+    if (!d_bases) return PandaGpuError::BasesIndexErr;
+    void *d_scalars = nullptr;
+    PandaGpuError e = memory_alloc_and_copy(gm, scalars, gm.get_h2d_stream(), &d_scalars);
+    if (e != PandaGpuError::Ok) return e;
+    if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+    return run_msm(gm, d_scalars, d_bases, log_2(scalars.len / FIELD_ELEMENT_LEN), true, false, result);
+}
+
+PandaGpuError panda_msm_bn254_gpu_with_cached_scalars(const PandaGpuManager &gm, size_t scalars_index, Bytes bases, std::vector<uint8_t> *result)
+{
+    void *d_scalars = gm.get_params_scalars_ptr_mut(scalars_index);
+    if (!d_scalars) return PandaGpuError::BasesIndexErr;
+    void *d_bases = nullptr;
+    PandaGpuError e = memory_alloc_and_copy(gm, bases, gm.get_h2d_stream(), &d_bases);
+    if (e != PandaGpuError::Ok) return e;
+    if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+    return run_msm(gm, d_scalars, d_bases, log_2(bases.len / (2 * FIELD_ELEMENT_LEN)), false, true, result); // unit.rs:203
+}
+
+PandaGpuError panda_msm_bn254_gpu_with_cached_input(const PandaGpuManager &gm, size_t scalars_index, size_t bases_index, std::vector<uint8_t> *result)
+{
+    void *d_scalars = gm.get_params_scalars_ptr_mut(scalars_index);
+    void *d_bases = gm.get_params_bases_ptr_mut(bases_index);
+    if (!d_scalars || !d_bases) return PandaGpuError::BasesIndexErr;
+    return run_msm(gm, d_scalars, d_bases, log_2(gm.get_params_scalars_len(scalars_index) / FIELD_ELEMENT_LEN), false, false, result);
+}
+
+PandaGpuError panda_msm_bn254_gpu_host(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result)
+{
+    const size_t result_buf_len = FIELD_ELEMENT_LEN * 3;
+    void *host = nullptr;
+    if (panda_malloc_host(&host, result_buf_len) != 0) return PandaGpuError::CreateContextError;
+    panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), const_cast<uint8_t *>(bases.data), const_cast<uint8_t *>(scalars.data), host,
+                                log_2(scalars.len / FIELD_ELEMENT_LEN), gm.get_msm_result_coordinate_type()};
+    const bool ok = panda_msm_execute_bn254_host(cfg) == 0;
+    if (ok) result->assign((uint8_t *)host, (uint8_t *)host + result_buf_len);
+    panda_free_host(host);
+    return ok ? PandaGpuError::Ok : PandaGpuError::SchedulingErr;
+}
+
+namespace {
+enum class NttKind { Global, V1, Inverse };
+
+PandaGpuError run_ntt(const PandaGpuManager &gm, uint8_t *scalars, size_t len, const Bytes *omega, uint32_t log_n, NttKind kind)
+{
+    assert(len == ((size_t)1 << log_n) * 32); // unit.rs:423
+    void *d_src = nullptr, *d_dst = nullptr;
+    PandaGpuError e = memory_alloc_and_copy(gm, Bytes{scalars, len}, gm.get_h2d_stream(), &d_src);
+    if (e != PandaGpuError::Ok) return e;
+    if ((e = malloc_from_pool_async(&d_dst, len, gm.get_mem_pool(), gm.get_h2d_stream())) != PandaGpuError::Ok) return e;
+    unsigned flag = 0;
+    panda_error rc;
+    if (kind == NttKind::Global) {
+        panda_ntt_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_src, d_dst, log_n, &flag};
+        rc = panda_ntt_execute_bn254(cfg);
+    } else {
+        panda_ntt_configuration_v1 cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_src, d_dst, const_cast<uint8_t *>(omega->data), log_n, &flag};
+        rc = kind == NttKind::V1 ? panda_ntt_execute_bn254_v1(cfg) : panda_ntt_execute_bn254_inverse(cfg);
+    }
+    if (rc != 0) return PandaGpuError::SchedulingErr;
+    if (panda_memcpy(scalars, flag == 0 ? d_src : d_dst, len) != 0) return PandaGpuError::CreateContextError; // unit.rs:521-532
+    if (panda_free(d_src) != 0 || panda_free(d_dst) != 0) return PandaGpuError::CreateContextError;
+    return PandaGpuError::Ok;
+}
+} // namespace
+
+PandaGpuError panda_ntt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, size_t len, uint32_t log_n)
+{
+    return run_ntt(gm, scalars, len, nullptr, log_n, NttKind::Global);
+}
+
+PandaGpuError panda_ntt_bn254_gpu_v1(const PandaGpuManager &gm, uint8_t *scalars, size_t len, Bytes omega, uint32_t log_n)
+{
+    return run_ntt(gm, scalars, len, &omega, log_n, NttKind::V1);
+}
+
+PandaGpuError panda_intt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, size_t len, Bytes omega, uint32_t log_n)
+{
+    return run_ntt(gm, scalars, len, &omega, log_n, NttKind::Inverse);
+}
+
+} // namespace panda_host

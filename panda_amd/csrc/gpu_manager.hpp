@@ -1,0 +1,130 @@
+// gpu_manager.hpp -- C++ mirror of the reference's Rust host layer (src/gpu_manager/{wrapper,unit,common}.rs)
+// over the C ABI in include/panda_interface.h.
+//
+// The reference's host side is compiled Rust; this image has no rustc, so the same layer is written in C++:
+// same type and function names, same ownership (the manager owns device id, memory pool and four streams,
+// wrapper.rs:8-19), same staging protocol (H2D on the h2d stream, event, execute on the exec stream, D2H,
+// free; unit.rs:10-101) and the same error enum (gpu_ffi/common.rs:5-38) returned instead of Result<_, _>.
+// Deliberate differences: the pinned result buffer is freed (the reference leaks it, unit.rs:67-100), and
+// cached scalars stay valid across calls because the library does not overwrite them.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/panda_interface.h"
+
+namespace panda_host {
+
+enum class PandaGpuError { // gpu_ffi/common.rs:5-38, plus Ok
+    Ok = 0,
+    GetDeviceCountError,
+    SetDeviceError,
+    DeviceGetDeviceMemoryInfoError,
+    CreateContextError,
+    InitUnitTypeError,
+    MSMBasesAddrError,
+    NTTOmegaAddrError,
+    SetBasesErr,
+    SchedulingErr,
+    GetExponentAddressErr,
+    GetResultAddressesErr,
+    StartProcessingErr,
+    FinishProcessingErr,
+    DestroyContextErr,
+    BasesIndexErr,
+    MemPoolCreateErr,
+    AsyncPoolMallocErr,
+    AsyncMemcopyErr,
+    NttExecErr,
+    StremCreateErr,
+    StreamDestroyErr,
+    StreamWaitEventErr,
+    StreamSyncErr,
+    EventCreateErr,
+    EventRecordErr,
+    EventDestroyErr,
+    EventSyncErr,
+};
+
+enum class PandaGpuManagerInitUnitType { None, MSM, NTT, ALL }; // wrapper.rs:23-29
+
+constexpr size_t FIELD_ELEMENT_LEN = 32; // gpu_manager/mod.rs:14
+
+struct Bytes { // &[u8]
+    const uint8_t *data;
+    size_t len;
+};
+
+struct PandaDeviceInfo {
+    uint64_t free, total;
+};
+
+inline uint32_t log_2(size_t num) // gpu_manager/common.rs:5-15
+{
+    uint32_t pow = 0;
+    while (((size_t)1 << (pow + 1)) <= num) pow++;
+    return pow;
+}
+
+PandaGpuError get_device_number(int *count);              // wrapper.rs:315-323
+PandaGpuError device_info(int device_id, PandaDeviceInfo *out); // wrapper.rs:325-338
+PandaGpuError set_device(size_t device_id);               // wrapper.rs:340-347
+
+class PandaGpuManager {
+  public:
+    // PandaGpuManager::new (wrapper.rs:32-53)
+    static PandaGpuError create(size_t device_id, PandaGpuManager *out);
+    // PandaGpuManager::init_all (wrapper.rs:55-113)
+    static PandaGpuError init_all(size_t device_id, PandaGpuManagerInitUnitType type, const std::vector<Bytes> *bases, const Bytes *omega,
+                                  PandaGpuManager *out);
+    static PandaGpuError init_hardware(size_t device_id, panda_mem_pool *pool);          // wrapper.rs:115-120
+    static PandaGpuError init_msm(const std::vector<Bytes> &bases, std::vector<void *> *d_ptrs); // wrapper.rs:122-152
+    static PandaGpuError init_msm_cached_bases(Bytes bases, void **d_ptr);               // wrapper.rs:154-169
+    static PandaGpuError init_msm_cached_scalars(Bytes scalars, void **d_ptr);           // wrapper.rs:171-186
+    static PandaGpuError init_ntt(Bytes omega);                                          // wrapper.rs:199-210
+
+    void set_config(panda_msm_result_coordinate_type t) { msm_result_coordinate_type_ = t; } // wrapper.rs:212-214
+    panda_mem_pool get_mem_pool() const { return mem_pool_; }
+    panda_stream get_stream() const { return default_stream_; }
+    panda_stream get_h2d_stream() const { return h2d_stream_; }
+    panda_stream get_d2h_stream() const { return d2h_stream_; }
+    panda_stream get_exec_stream() const { return exec_stream_; }
+    panda_msm_result_coordinate_type get_msm_result_coordinate_type() const { return msm_result_coordinate_type_; }
+    void *get_params_bases_ptr_mut(size_t index) const { return index < d_bases.size() ? d_bases[index] : nullptr; }
+    void *get_params_scalars_ptr_mut(size_t index) const { return index < d_scalars.size() ? d_scalars[index] : nullptr; }
+    size_t get_params_scalars_len(size_t index) const { return index < scalars_len.size() ? scalars_len[index] : 0; }
+    PandaGpuError wait_h2d() const; // wrapper.rs:260-266
+    PandaGpuError wait_exec() const; // wrapper.rs:268-273
+    PandaGpuError sync() const;      // wrapper.rs:285-291
+    size_t device_id() const { return device_id_; }
+    PandaGpuError deinit();          // wrapper.rs:297-312 (also releases streams and the library's scratch)
+
+    std::vector<void *> d_bases, d_scalars; // pub in the reference (wrapper.rs:15-17)
+    std::vector<size_t> scalars_len;
+
+  private:
+    size_t device_id_ = 0;
+    panda_mem_pool mem_pool_{};
+    panda_stream default_stream_{}, h2d_stream_{}, d2h_stream_{}, exec_stream_{};
+    panda_msm_result_coordinate_type msm_result_coordinate_type_ = JACOBIAN;
+};
+
+// gpu_manager/common.rs:17-76
+PandaGpuError malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool pool, panda_stream stream);
+PandaGpuError memcpy_async(void *dst, const void *src, size_t size, panda_stream stream);
+PandaGpuError free_async(void *ptr, panda_stream stream);
+PandaGpuError memory_alloc_and_copy(const PandaGpuManager &gm, Bytes h_values, panda_stream stream, void **d_values);
+
+// gpu_manager/unit.rs -- results are 96 bytes X||Y||Z (Montgomery limbs)
+PandaGpuError panda_msm_bn254_gpu(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result);                    // :10-101
+PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, Bytes scalars, size_t bases_index, std::vector<uint8_t> *result);   // :103-188
+PandaGpuError panda_msm_bn254_gpu_with_cached_scalars(const PandaGpuManager &gm, size_t scalars_index, Bytes bases, std::vector<uint8_t> *result); // :190-275
+PandaGpuError panda_msm_bn254_gpu_with_cached_input(const PandaGpuManager &gm, size_t scalars_index, size_t bases_index, std::vector<uint8_t> *result); // :277-361
+PandaGpuError panda_msm_bn254_gpu_host(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result);               // :363-416
+PandaGpuError panda_ntt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, size_t len, uint32_t log_n);                                // :418-479
+PandaGpuError panda_ntt_bn254_gpu_v1(const PandaGpuManager &gm, uint8_t *scalars, size_t len, Bytes omega, uint32_t log_n);                // :481-543
+// additive: inverse transform with n^-1 fused
+PandaGpuError panda_intt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, size_t len, Bytes omega, uint32_t log_n);
+
+} // namespace panda_host

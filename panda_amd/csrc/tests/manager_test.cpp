@@ -1,0 +1,138 @@
+// manager_test.cpp -- C++ counterpart of the reference's Rust integration tests (tests/test.rs:50-194) on top of the
+// C++ gpu_manager mirror: random points and scalars, device MSM vs the library's CPU host-debug entry point,
+// equality asserted on the affine-normalised result (tests/test.rs:101-108); plus the cached-input variants and an
+// NTT forward/inverse round trip.  Independent parity against the oracle lives in tests/test_gpu_parity.py.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../curve29.h"
+#include "../gpu_manager.hpp"
+
+using namespace panda_host;
+using namespace panda29;
+
+#define REQUIRE(cond)                                                   \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);    \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+static std::vector<uint8_t> affine_of(const std::vector<uint8_t> &xyz, bool homogeneous)
+{
+    typedef Bn254Fq F;
+    std::vector<uint8_t> out(64, 0);
+    const u32 *w = (const u32 *)xyz.data();
+    Fe<F> x, y, z;
+    fe_from_wire(z, w + 16);
+    if (fe_is_zero_2p(z)) return out; // identity: all zero marker
+    Fe<F> zi, zi2, zi3;
+    fe_inv(zi, z);
+    fe_from_wire(x, w);
+    fe_from_wire(y, w + 8);
+    if (homogeneous) {
+        fe_mul(x, x, zi);
+        fe_mul(y, y, zi);
+    } else {
+        fe_sqr(zi2, zi);
+        fe_mul(zi3, zi2, zi);
+        fe_mul(x, x, zi2);
+        fe_mul(y, y, zi3);
+    }
+    fe_to_wire((u32 *)out.data(), x);
+    fe_to_wire((u32 *)out.data() + 8, y);
+    return out;
+}
+
+static void root_of_unity(u32 *omega_wire, unsigned log_n)
+{
+    typedef Bn254Fr F;
+    // 7^((r - 1) / 2^28), squared down to order 2^log_n (bn254/paramter.cuh:241-258)
+    u32 e[8];
+    for (int i = 0; i < 8; i++) e[i] = F::PW[i];
+    e[0] -= 1;
+    for (int s = 0; s < 28; s++) {
+        for (int i = 0; i < 7; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 31);
+        e[7] >>= 1;
+    }
+    Fe<F> g, acc;
+    fe_from_u32(g, 7);
+    fe_one(acc);
+    for (int bit = 255; bit >= 0; bit--) {
+        fe_sqr(acc, acc);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) fe_mul(acc, acc, g);
+    }
+    for (unsigned s = log_n; s < 28; s++) fe_sqr(acc, acc);
+    fe_to_wire(omega_wire, acc);
+}
+
+int main()
+{
+    PandaGpuManager gm;
+    REQUIRE(PandaGpuManager::create(0, &gm) == PandaGpuError::Ok);
+
+    for (unsigned k : {10u, 12u, 14u, 16u}) { // test_msm_bn254_correctness_device
+        const size_t n = (size_t)1 << k;
+        std::vector<uint8_t> bases(n * 64), scalars(n * 32);
+        void *d = nullptr;
+        REQUIRE(panda_malloc(&d, n * 64) == 0);
+        REQUIRE(panda_gen_bases(0, 1000 + k, 0, n, d, gm.get_exec_stream()) == 0);
+        REQUIRE(panda_memcpy(bases.data(), d, n * 64) == 0);
+        REQUIRE(panda_gen_scalars(0, 2000 + k, 0, n, d, gm.get_exec_stream()) == 0);
+        REQUIRE(panda_memcpy(scalars.data(), d, n * 32) == 0);
+        REQUIRE(panda_free(d) == 0);
+        std::vector<uint8_t> keep = scalars, gpu, cpu;
+        REQUIRE(panda_msm_bn254_gpu(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &gpu) == PandaGpuError::Ok);
+        REQUIRE(scalars == keep);
+        if (k <= 12) { // test_msm_bn254_correctness_host: the CPU entry point as comparator
+            REQUIRE(panda_msm_bn254_gpu_host(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &cpu) == PandaGpuError::Ok);
+            REQUIRE(affine_of(gpu, false) == affine_of(cpu, false));
+        }
+        // cached variants must agree with the staged call, twice over (scalars are not consumed)
+        void *db = nullptr, *ds = nullptr;
+        REQUIRE(PandaGpuManager::init_msm_cached_bases(Bytes{bases.data(), bases.size()}, &db) == PandaGpuError::Ok);
+        REQUIRE(PandaGpuManager::init_msm_cached_scalars(Bytes{scalars.data(), scalars.size()}, &ds) == PandaGpuError::Ok);
+        gm.d_bases.push_back(db);
+        gm.d_scalars.push_back(ds);
+        gm.scalars_len.push_back(scalars.size());
+        const size_t bi = gm.d_bases.size() - 1, si = gm.d_scalars.size() - 1;
+        std::vector<uint8_t> r1, r2, r3, r4;
+        REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, bi, &r1) == PandaGpuError::Ok);
+        REQUIRE(panda_msm_bn254_gpu_with_cached_scalars(gm, si, Bytes{bases.data(), bases.size()}, &r2) == PandaGpuError::Ok);
+        REQUIRE(panda_msm_bn254_gpu_with_cached_input(gm, si, bi, &r3) == PandaGpuError::Ok);
+        gm.set_config(PROJECTIVE);
+        REQUIRE(panda_msm_bn254_gpu_with_cached_input(gm, si, bi, &r4) == PandaGpuError::Ok);
+        gm.set_config(JACOBIAN);
+        const std::vector<uint8_t> want = affine_of(gpu, false);
+        REQUIRE(affine_of(r1, false) == want && affine_of(r2, false) == want && affine_of(r3, false) == want && affine_of(r4, true) == want);
+        REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, 99, &r1) == PandaGpuError::BasesIndexErr);
+        printf("Run k = %u, compare successfully\n", k);
+    }
+
+    for (unsigned log_n : {4u, 10u, 17u}) { // NTT: v1 forward, global-omega forward, inverse
+        const size_t n = (size_t)1 << log_n;
+        std::vector<uint8_t> x(n * 32);
+        void *d = nullptr;
+        REQUIRE(panda_malloc(&d, n * 32) == 0);
+        REQUIRE(panda_gen_scalars(0, 3000 + log_n, 0, n, d, gm.get_exec_stream()) == 0);
+        REQUIRE(panda_memcpy(x.data(), d, n * 32) == 0);
+        REQUIRE(panda_free(d) == 0);
+        u32 omega[8];
+        root_of_unity(omega, log_n);
+        Bytes om{(const uint8_t *)omega, 32};
+        std::vector<uint8_t> a = x, b = x;
+        REQUIRE(panda_ntt_bn254_gpu_v1(gm, a.data(), a.size(), om, log_n) == PandaGpuError::Ok);
+        REQUIRE(a != x);
+        REQUIRE(PandaGpuManager::init_ntt(om) == PandaGpuError::Ok);
+        REQUIRE(panda_ntt_bn254_gpu(gm, b.data(), b.size(), log_n) == PandaGpuError::Ok);
+        REQUIRE(a == b);
+        REQUIRE(panda_intt_bn254_gpu(gm, a.data(), a.size(), om, log_n) == PandaGpuError::Ok);
+        REQUIRE(a == x);
+        printf("NTT log_n = %u round trip ok\n", log_n);
+    }
+    REQUIRE(gm.deinit() == PandaGpuError::Ok);
+    printf("manager_test: all ok\n");
+    return 0;
+}

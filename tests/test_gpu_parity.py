@@ -374,3 +374,14 @@ def test_ntt_slab_steps_single_gpu(gm, log_ranks, log_n):
         d_slab.free()
         d_scr.free()
     assert (multi_gpu.natural_from_slab_outputs(outs) == po.ntt(fid, x, om, log_n)).all()
+
+
+def test_cpp_gpu_manager_mirror():
+    """The C++ mirror of the reference's Rust gpu_manager + its integration test binary (panda_amd/csrc/tests/manager_test.cpp,
+    the counterpart of tests/test.rs): device MSM vs the CPU entry point, cached variants, NTT round trips."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(ffi.LIB_PATH), "tests", "manager_test")
+    assert os.path.exists(exe), "build it with make -C panda_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "manager_test: all ok" in r.stdout
