@@ -101,19 +101,26 @@ __device__ __forceinline__ void store_elem(u32 *__restrict__ dst, const Fe<Fr> &
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); }
 
-// LDS image of field elements as NL limb planes of STRIDE words: lane e of a wave touches word e of each plane
-template <int STRIDE>
+// LDS image of field elements as NL limb planes: element e lives at word pad(e) = e + (e >> 5) of each plane.
+// The one-word pad per 32 elements makes every access pattern of a pass conflict-free or 2-way at worst:
+// unit stride (butterflies with bit >= 32), stride 2 (last rounds), stride 256 (the gather from HBM puts consecutive
+// lanes into different sub-transforms) and the bit-reversed read-out.
+template <int COUNT>
 struct Planes {
+    static constexpr int STRIDE = COUNT + COUNT / 32;
     u32 *base;
+    __device__ __forceinline__ static unsigned pad(unsigned e) { return e + (e >> 5); }
     __device__ __forceinline__ void load(Fe<Fr> &r, unsigned e) const
     {
+        const unsigned p = pad(e);
 #pragma unroll
-        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + e];
+        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + p];
     }
     __device__ __forceinline__ void store(const Fe<Fr> &r, unsigned e) const
     {
+        const unsigned p = pad(e);
 #pragma unroll
-        for (int i = 0; i < NL; i++) base[i * STRIDE + e] = r.l[i];
+        for (int i = 0; i < NL; i++) base[i * STRIDE + p] = r.l[i];
     }
 };
 typedef Planes<TILE> TilePlanes;
@@ -175,8 +182,8 @@ template <int DEG>
 __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
 {
     constexpr unsigned R = 1u << DEG;
-    __shared__ u32 s_u[NL * TILE];
-    __shared__ u32 s_pq[NL * 128];
+    __shared__ u32 s_u[NL * TilePlanes::STRIDE];
+    __shared__ u32 s_pq[NL * TwiddlePlanes::STRIDE];
     const TilePlanes u{s_u};
     const TwiddlePlanes pq{s_pq};
     const unsigned tid = threadIdx.x;
