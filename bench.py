@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the contract) or gloo (rehearsal of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--all-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -76,10 +78,15 @@ def main():
     from panda_amd import gpu_ffi as ffi
     from panda_amd import multi_gpu
 
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     lib = ffi.load()
     ffi.check(lib.panda_set_device(local_rank), "SetDeviceError")
 
@@ -104,9 +111,13 @@ def main():
             lib.panda_msm_last_phase_ms(phase)
             acc_ms.append(list(phase))
         if world > 1:
-            gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(gathered, result)
-            multi_gpu.combine_partials(gathered.cpu().numpy().reshape(world, 96))
+            if args.dist_backend == "nccl":  # 96 B per rank over RCCL, device buffers
+                gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(gathered, result)
+                partials = gathered.cpu().numpy().reshape(world, 96)
+            else:
+                partials = multi_gpu.allgather_partials(result.cpu().numpy())
+            step.total = multi_gpu.combine_partials(partials)
 
     def fence():
         if world > 1:
@@ -123,7 +134,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -156,7 +167,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BN254 MSM 2^{log_n} points per GPU, Jacobian output, bases and scalars resident in HBM",
                        "curve": "bn254", "log_points_per_gpu": log_n, "sharding": f"base-range x{world}" if world > 1 else "none",
-                       "exchange": "all-gather of 96 B partials (RCCL) + host point additions" if world > 1 else "none"},
+                       "exchange": f"all-gather of 96 B partials ({'RCCL' if args.dist_backend == 'nccl' else args.dist_backend}) + host point additions" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * n, "kernel_ms": acc_kernel_ms},

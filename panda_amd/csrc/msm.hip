@@ -294,11 +294,13 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ tile_hist,
     if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
 }
 
-// block-wide exclusive scan of `count` (<= 1024) LDS words in place, 256 threads; returns nothing, callers re-sync
-__device__ __forceinline__ void block_exclusive_scan_256(u32 *a, unsigned count, u32 *scratch /* 256 words */)
+constexpr unsigned SORT_THREADS = 1024; // 16 waves per workgroup: these kernels wait on LDS atomics and HBM, they need the occupancy
+
+// block-wide exclusive scan of `count` (<= 1024) LDS words in place by SORT_THREADS threads
+__device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32 *scratch /* SORT_THREADS words */)
 {
     const unsigned tid = threadIdx.x;
-    const unsigned per = (count + 255) / 256;
+    const unsigned per = (count + SORT_THREADS - 1) / SORT_THREADS;
     u32 local = 0;
     for (unsigned j = 0; j < per; j++) {
         unsigned i = tid * per + j;
@@ -306,7 +308,7 @@ __device__ __forceinline__ void block_exclusive_scan_256(u32 *a, unsigned count,
     }
     scratch[tid] = local;
     __syncthreads();
-    for (unsigned d = 1; d < 256; d <<= 1) {
+    for (unsigned d = 1; d < SORT_THREADS; d <<= 1) {
         u32 v = (tid >= d) ? scratch[tid - d] : 0;
         __syncthreads();
         scratch[tid] += v;
@@ -327,7 +329,7 @@ __device__ __forceinline__ void block_exclusive_scan_256(u32 *a, unsigned count,
 // word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n].
 // The tile is first grouped by partition in LDS (local counting sort), then written out linearly, so that a wave
 // stores runs of consecutive addresses instead of 64 unrelated 4-byte words.
-__global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
+__global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const uint16_t *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
                                                       u32 *__restrict__ p1, SortGeom g)
 {
     __shared__ u32 lstart[MAX_PARTS]; // local start of each partition's run in the staging buffer
@@ -335,11 +337,11 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict
     __shared__ u32 gbase[MAX_PARTS];  // global position of this tile's first element of the partition
     __shared__ u32 words[SORT_TILE];
     __shared__ uint16_t parts_of[SORT_TILE];
-    __shared__ u32 scratch[256];
+    __shared__ u32 scratch[SORT_THREADS];
     const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
     const u32 *po = part_off + (u64)w * (g.H + 1);
-    for (unsigned i = tid; i < g.H; i += 256) {
+    for (unsigned i = tid; i < g.H; i += SORT_THREADS) {
         lstart[i] = 0;
         lcur[i] = 0;
         gbase[i] = po[i] + base[i];
@@ -350,13 +352,13 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict
     u32 *pw = p1 + ((u64)w << g.log_n);
     const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
     const u32 lo_mask = (1u << g.lo_bits) - 1;
-    for (u64 i = begin + tid; i < end; i += 256) {
+    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
         u32 code = dw[i];
         if (code != DIGIT_ZERO) atomicAdd(&lstart[(code & 0x7fffu) >> g.lo_bits], 1u);
     }
     __syncthreads();
-    block_exclusive_scan_256(lstart, g.H, scratch);
-    for (u64 i = begin + tid; i < end; i += 256) {
+    block_exclusive_scan(lstart, g.H, scratch);
+    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
         u32 code = dw[i];
         if (code == DIGIT_ZERO) continue;
         u32 b = code & 0x7fffu, h = b >> g.lo_bits;
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict
     }
     __syncthreads();
     const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
-    for (u32 j = tid; j < total; j += 256) {
+    for (u32 j = tid; j < total; j += SORT_THREADS) {
         u32 h = parts_of[j];
         pw[gbase[h] + (j - lstart[h])] = words[j];
     }
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t *__restrict
 // chunk in LDS and write each chunk out as runs
 constexpr unsigned BS_CHUNK = 8192;
 
-__global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
+__global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
                                                      u32 *__restrict__ sorted, SortGeom g, unsigned NB)
 {
     __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1,
     const unsigned shift = g.log_n + 1;
     if (tid < 128) cnt[tid] = 0;
     __syncthreads();
-    for (u32 j = ps + tid; j < pe; j += 256) atomicAdd(&cnt[pw[j] >> shift], 1u);
+    for (u32 j = ps + tid; j < pe; j += SORT_THREADS) atomicAdd(&cnt[pw[j] >> shift], 1u);
     __syncthreads();
     u32 mine = tid < 128 ? cnt[tid] : 0;
     for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1,
             lcur[tid] = 0;
         }
         __syncthreads();
-        for (u32 j = cbeg + tid; j < cend; j += 256) atomicAdd(&lstart[pw[j] >> shift], 1u);
+        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) atomicAdd(&lstart[pw[j] >> shift], 1u);
         __syncthreads();
         u32 c0 = tid < 128 ? lstart[tid] : 0;
         for (unsigned d = 1; d < 128; d <<= 1) {
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1,
             cnt[tid] = c0;
         }
         __syncthreads();
-        for (u32 j = cbeg + tid; j < cend; j += 256) {
+        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) {
             u32 v = pw[j];
             u32 l = v >> shift;
             u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const u32 *__restrict__ p1,
             lo_of[slot] = (unsigned char)l;
         }
         __syncthreads();
-        for (u32 j = tid; j < cend - cbeg; j += 256) {
+        for (u32 j = tid; j < cend - cbeg; j += SORT_THREADS) {
             u32 l = lo_of[j];
             sw[cur[l] + (j - lstart[l])] = words[j];
         }
@@ -803,9 +805,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     PANDA_TRY(mark(1));
     hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
     hipLaunchKernelGGL(k_part_scan, dim3(W), dim3(1024), 0, stream, d_thist, d_poff, geom);
-    hipLaunchKernelGGL(k_part_scatter, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
+    hipLaunchKernelGGL(k_part_scatter, dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
     PANDA_TRY(mark(2));
-    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(256), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
+    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
     PANDA_TRY(mark(3));
     PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, W), dim3(128), 0, stream, d_bases, d_sorted, d_off, d_bacc, d_parts, log_n, NB, K,
