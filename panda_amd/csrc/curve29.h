@@ -13,7 +13,7 @@
 // Identity is encoded as ZZ == 0 (all limbs zero), mirroring "z == 0" (projective.cuh:111-114).
 //
 // Lazy-reduction invariants on stored points (units of p; M = SubMargin<F>):
-//   X < (8+M) p loose, Y < (4+M) p loose, ZZ, ZZZ < 2p tight.
+//   X < (8+M) p loose, Y < YB p (2p after an addition; k p - y when the accumulator was seeded with a negated base), ZZ, ZZZ < 2p tight.
 // Each formula below lists the bound of every intermediate; fe_mul needs value(a)*value(b) < 0.9 R p,
 // i.e. (bound a)*(bound b) < 0.9 * HEADROOM, which the static_asserts check per field.
 #pragma once
@@ -29,17 +29,18 @@ struct Xyzz {
 template <class F>
 struct Bounds {
     static constexpr int M = SubMargin<F>::value;
-    static constexpr int XB = 8 + M;  // stored X
-    static constexpr int YB = 4 + M;  // stored Y
+    static constexpr int XB = 8 + M;  // stored X (loose)
+    static constexpr int YB = SubGrowth<F, 2>::value; // stored Y: < 2p out of fe_mul_add, or a negated base coordinate k p - y
     static constexpr int PB = 2 + SubGrowth<F, XB>::value; // P = U2 - X1 + k p
     static constexpr int RB = 2 + SubGrowth<F, YB>::value; // R = S2 - Y1 + k p
     static constexpr int VB = 2 + SubGrowth<F, XB>::value; // Q - X3 + k p
     static constexpr long long LIM = F::HEADROOM * 9 / 10;
     static_assert((long long)PB * PB < LIM, "P^2 exceeds the lazy-reduction headroom");
-    static_assert((long long)RB * VB < LIM, "R*(Q-X3) exceeds the lazy-reduction headroom");
+    static constexpr int NB = SubGrowth<F, 2>::value; // -PPP, -W: k p - (a value below 2p)
+    static_assert((long long)RB * VB + (long long)YB * NB < LIM, "R*(Q-X3) - Y1*PPP exceeds the lazy-reduction headroom");
+    static_assert(6LL * VB + 2LL * NB < LIM, "3x^2*(S-X3) - W*Y exceeds the lazy-reduction headroom");
     static_assert((long long)(2 * YB) * (2 * YB) < LIM, "(2Y)^2 exceeds the lazy-reduction headroom");
     static_assert(2 + SubGrowth<F, 6>::value <= XB, "X3 bound");
-    static_assert(2 + SubGrowth<F, 2>::value <= YB, "Y3 bound");
 };
 
 template <class F>
@@ -71,15 +72,14 @@ template <class F>
 PANDA_HD void xyzz_finish(Fe<F> &X3, Fe<F> &Y3, const Fe<F> &R, const Fe<F> &Q, const Fe<F> &PPP, const Fe<F> &S1)
 {
     typedef Bounds<F> B;
-    Fe<F> t, rr, v, t1, t2;
+    Fe<F> t, rr, v, nppp;
     fe_add_nr(t, Q, Q);       // 2Q      < 4p raw
     fe_add_nr(t, t, PPP);     // + PPP   < 6p, limbs < 3*2^29
     fe_sqr(rr, R);            // R^2     < 2p
     fe_sub<F, 6>(X3, rr, t);  // X3      < (2 + 6+M) p = XB p
     fe_sub<F, B::XB>(v, Q, X3); // Q - X3 < VB p
-    fe_mul(t1, R, v);         // < 2p
-    fe_mul(t2, S1, PPP);      // < 2p   (S1 < YB p loose or < 2p)
-    fe_sub<F, 2>(Y3, t1, t2); // Y3      < (2 + 2+M) p = YB p
+    fe_neg<F, 2>(nppp, PPP);  // k p - PPP < NB p
+    fe_mul_add(Y3, R, v, S1, nppp); // (R (Q - X3) - S1 PPP) / R: one reduction for both products; tight, < 2p
 }
 
 // 2 * (x, y) for an affine point (mdbl-2008-s-1); x, y tight < 2p
@@ -104,9 +104,8 @@ PANDA_HD void xyzz_dbl_affine(Xyzz<F> &r, const Fe<F> &x, const Fe<F> &y)
     fe_add_nr(t, S, S);           // 2S < 4p raw
     fe_sub<F, 4>(r.X, t1, t);     // < (2+4+M) p <= XB p
     fe_sub<F, B::XB>(v, S, r.X);  // < VB p
-    fe_mul(t1, M3, v);            // 6 * VB
-    fe_mul(t2, W, y);
-    fe_sub<F, 2>(r.Y, t1, t2);
+    fe_neg<F, 2>(t2, W);
+    fe_mul_add(r.Y, M3, v, t2, y); // (3x^2 (S - X3) - W y) / R
     r.ZZ = V;
     r.ZZZ = W;
 }
@@ -137,9 +136,8 @@ PANDA_HD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &p)
     fe_add_nr(t, S, S);
     fe_sub<F, 4>(X3, t1, t);
     fe_sub<F, B::XB>(v, S, X3);
-    fe_mul(t1, M3, v);
-    fe_mul(t2, W, p.Y);
-    fe_sub<F, 2>(Y3, t1, t2);
+    fe_neg<F, 2>(t2, W);
+    fe_mul_add(Y3, M3, v, t2, p.Y);
     fe_mul(t, V, p.ZZ);
     fe_mul(t2, W, p.ZZZ);
     r.X = X3;

@@ -268,21 +268,35 @@ __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ 
     for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
 }
 
-// one block per window: tile_hist -> exclusive prefix over tiles (in place), partition offsets part_off[w][0..H]
-__global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ tile_hist, u32 *__restrict__ part_off, SortGeom g)
+// tile_hist -> exclusive prefix over tiles (in place), one WAVE per (window, partition) column: 64 tiles per step with a
+// shuffle scan instead of one dependent load per tile; column totals go to `totals`
+__global__ void __launch_bounds__(1024) k_part_scan_cols(u32 *__restrict__ tile_hist, u32 *__restrict__ totals, SortGeom g)
+{
+    const unsigned w = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (h >= g.H) return; // whole wave exits together
+    u32 *col = tile_hist + (u64)w * g.tiles * g.H + h;
+    u32 run = 0;
+    for (unsigned t0 = 0; t0 < g.tiles; t0 += 64) {
+        const unsigned tile = t0 + lane;
+        u32 v = tile < g.tiles ? col[(u64)tile * g.H] : 0;
+        u32 inc = v;
+        for (unsigned d = 1; d < 64; d <<= 1) {
+            u32 up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (tile < g.tiles) col[(u64)tile * g.H] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) totals[(u64)w * g.H + h] = run;
+}
+
+// one block per window: exclusive scan of the H column totals -> part_off[w][0..H]
+__global__ void __launch_bounds__(1024) k_part_offsets(const u32 *__restrict__ totals, u32 *__restrict__ part_off, SortGeom g)
 {
     __shared__ u32 tot[MAX_PARTS];
     const unsigned w = blockIdx.x, t = threadIdx.x;
-    u32 run = 0;
-    if (t < g.H) {
-        u32 *col = tile_hist + (u64)w * g.tiles * g.H + t;
-        for (unsigned tile = 0; tile < g.tiles; tile++) {
-            u32 v = col[(u64)tile * g.H];
-            col[(u64)tile * g.H] = run;
-            run += v;
-        }
-    }
-    tot[t] = run;
+    const u32 mine = t < g.H ? totals[(u64)w * g.H + t] : 0;
+    tot[t] = mine;
     __syncthreads();
     for (unsigned d = 1; d < 1024; d <<= 1) {
         u32 v = (t >= d) ? tot[t - d] : 0;
@@ -290,7 +304,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ tile_hist,
         tot[t] += v;
         __syncthreads();
     }
-    if (t < g.H) part_off[(u64)w * (g.H + 1) + t] = tot[t] - run;
+    if (t < g.H) part_off[(u64)w * (g.H + 1) + t] = tot[t] - mine;
     if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
 }
 
@@ -777,11 +791,12 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const size_t sz_lcount = panda::align256((size_t)W * 4);
     const size_t sz_llist = panda::align256((size_t)W * long_cap * 3 * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 4096));
+    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + 2 * sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 4096));
     u32 *d_bases = (u32 *)arena.take(sz_bases);
     uint16_t *d_dig = (uint16_t *)arena.take(sz_dig);
     u32 *d_thist = (u32 *)arena.take(sz_thist);
     u32 *d_poff = (u32 *)arena.take(sz_poff);
+    u32 *d_ptot = (u32 *)arena.take(sz_poff);
     u32 *d_p1 = (u32 *)arena.take(sz_sorted);
     u32 *d_off = (u32 *)arena.take(sz_off);
     u32 *d_sorted = (u32 *)arena.take(sz_sorted);
@@ -804,7 +819,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, plan);
     PANDA_TRY(mark(1));
     hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
-    hipLaunchKernelGGL(k_part_scan, dim3(W), dim3(1024), 0, stream, d_thist, d_poff, geom);
+    hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_ptot, geom);
+    hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, geom);
     hipLaunchKernelGGL(k_part_scatter, dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
     PANDA_TRY(mark(2));
     hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);

@@ -1,0 +1,60 @@
+"""Turns the rocprofv3 CSVs merged into gpurun_out/ (kernel stats + FETCH_SIZE / WRITE_SIZE passes) into the small
+summaries committed under profiles/.  usage: python tools/summarize_profiles.py <tag>   e.g. r01b"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, pattern)), key=os.path.getmtime)
+    return files[-1]
+
+
+def short(k):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([A-Za-z_0-9:]+)", k)
+    return m.group(1) if m else k[:30]
+
+
+def main():
+    tag = sys.argv[1]
+    shutil.copy(latest("gpurun_out/prof_stats/*/*_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
+    res = {}
+    for name in ("fetch", "write"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(latest(f"gpurun_out/prof_{name}/*/*_counter_collection.csv"))):
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        res[name] = agg
+    rows = []
+    for k in sorted(res["fetch"]):
+        if not k.startswith("k_"):
+            continue
+        fv, wv = res["fetch"][k], res["write"].get(k, [0])
+        f, w = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
+        rows.append((k, len(fv), f, 2 * f, w, 2 * f + w))
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_bytes.csv"), "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt (BN254 MSM 2^24)\n")
+        o.write("# bytes per launch = counter (KB) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane reads);\n")
+        o.write("# k_convert_bases calibrates the correction: it reads 2^24 * 64 B = 1.074 GB\n")
+        o.write("kernel,launches,fetch_size_raw_bytes,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
+        for r in rows:
+            o.write("%s,%d,%.0f,%.0f,%.0f,%.0f\n" % r)
+    acc = [r for r in rows if r[0] == "k_accumulate"][0]
+    json.dump({"round": tag, "log_n": 24, "k_accumulate_hbm_bytes_per_launch": acc[5], "fetch_corrected": acc[3], "write": acc[4],
+               "source": f"profiles/{tag}_pmc_hbm_bytes.csv"}, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    line = [l for l in open(os.path.join(ROOT, "gpurun_out", "prof_stats.log")) if l.startswith("{")]
+    if line:
+        open(os.path.join(ROOT, "profiles", f"{tag}_bench_line.json"), "w").write(line[-1])
+    print(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_bytes.csv")).read())
+    print(open(os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv")).read()[:3000])
+
+
+if __name__ == "__main__":
+    main()
