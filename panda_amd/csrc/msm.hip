@@ -867,14 +867,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
 
     float ms = 0;
     for (int i = 0; i < 6; i++) {
-        hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+        (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
         g_phase_ms[i] = ms;
     }
-    hipEventElapsedTime(&ms, ev[6], ev[7]);
+    (void)hipEventElapsedTime(&ms, ev[6], ev[7]);
     g_phase_ms[6] = ms;
-    hipEventElapsedTime(&ms, ev[0], ev[6]);
+    (void)hipEventElapsedTime(&ms, ev[0], ev[6]);
     g_phase_ms[7] = ms;
-    for (auto &e : ev) hipEventDestroy(e);
+    for (auto &e : ev) (void)hipEventDestroy(e);
     (void)LR;
     return hipSuccess;
 }
