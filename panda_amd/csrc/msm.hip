@@ -763,7 +763,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const unsigned W = plan.W;
     const unsigned c = plan.width[0]; // widest window
     const unsigned NB = 1u << (c - 1);
-    const unsigned K = log_n >= 22 ? 64 : (log_n >= 16 ? 32 : 16);
+    const unsigned K = log_n >= 24 ? 128 : (log_n >= 22 ? 64 : (log_n >= 16 ? 32 : 16)); // sorted entries per accumulate thread
     const unsigned chunks = (unsigned)((n + K - 1) / K);
     const unsigned groups = (NB + GROUP - 1) / GROUP;
     const unsigned lvl1 = (groups + 255) / 256 > 64 ? 64 : (groups + 255) / 256; // blocks in the first tree level
@@ -809,7 +809,15 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     u32 *d_llist = (u32 *)arena.take(sz_llist);
     if (!d_win || !d_llist) return hipErrorOutOfMemory;
 
-    hipEvent_t ev[8];
+    struct PhaseEvents { // destroyed on every exit path
+        hipEvent_t ev[8] = {};
+        ~PhaseEvents()
+        {
+            for (auto &e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } phase_events;
+    hipEvent_t(&ev)[8] = phase_events.ev;
     for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
     auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
 
@@ -874,7 +882,6 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     g_phase_ms[6] = ms;
     (void)hipEventElapsedTime(&ms, ev[0], ev[6]);
     g_phase_ms[7] = ms;
-    for (auto &e : ev) (void)hipEventDestroy(e);
     (void)LR;
     return hipSuccess;
 }
