@@ -254,3 +254,22 @@ def test_ntt_fast_vs_passes_roundtrip_linearity(log_n):
     lhs = po.ntt(fid, po.f_vec(fid, po.OP_ADD, x, z), om, log_n)
     rhs = po.f_vec(fid, po.OP_ADD, y, po.ntt(fid, z, om, log_n))
     assert (lhs == rhs).all()
+
+
+def test_committed_golden_cases_still_match_oracle(golden_dir):
+    """tests/golden/*.json were produced by tests/golden/make_golden.py; the oracle must keep reproducing them."""
+    import json
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden
+    cases = json.load(open(os.path.join(golden_dir, "msm_cases.json")))
+    for c in cases[:4] + cases[5:8]:
+        n = 1 << c["log_n"]
+        bases = np.tile(po.generator(0), (n, 1)) if c.get("bases") == "all_generator" else po.gen_bases(c["curve"], c["bases_seed"], n)
+        scalars = make_golden.scalar_set(c["scalars"], c["curve"], n, c["scalars_seed"])
+        assert po.msm_affine(c["curve"], bases, scalars, window_bits=9).tobytes().hex() == c["affine_hex"]
+    for c in json.load(open(os.path.join(golden_dir, "ntt_cases.json")))[:5]:
+        x = po.gen_scalars(po.F_BN254_FR, c["seed"], 1 << c["log_n"])
+        om = np.frombuffer(bytes.fromhex(c["omega_hex"]), dtype=np.uint32)
+        y = po.ntt(po.F_BN254_FR, x, om, c["log_n"])
+        assert hashlib.sha256(y.tobytes()).hexdigest() == c["sha256"]
