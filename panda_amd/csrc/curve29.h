@@ -146,36 +146,46 @@ PANDA_HD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &p)
     r.ZZZ = t2;
 }
 
-// acc += (bx, by); bx, by tight < 2p; base_identity <=> the wire x was 0 (affine.cuh:72-75).  8M + 2S.
+// acc += (bx, by) for a non-identity accumulator and base; bx, by tight < 2p.  8M + 2S.
+// Returns 0 when done.  When the two points share their x coordinate nothing is written and the caller finishes the
+// job: 1 = same point (double the BASE, xyzz_dbl_affine), 2 = opposite points (the sum is the identity).
+// Splitting the rare cases off keeps bx, by dead after the first two products (register pressure in k_accumulate).
+template <class F>
+PANDA_HD int xyzz_madd_core(Xyzz<F> &acc, const Fe<F> &bx, const Fe<F> &by)
+{
+    typedef Bounds<F> B;
+    Fe<F> U2, S2, P, R, PP, PPP, Q, X3, Y3;
+    fe_mul(U2, bx, acc.ZZ);
+    fe_sub<F, B::XB>(P, U2, acc.X); // < PB p
+    fe_mul(S2, by, acc.ZZZ);
+    fe_sub<F, B::YB>(R, S2, acc.Y); // < RB p
+    fe_sqr(PP, P);
+    if (fe_is_zero_2p(PP)) // same x: P + P or P + (-P)   (projective.cuh:284-288)
+        return fe_is_zero_mod_p(R) ? 1 : 2;
+    fe_mul(PPP, P, PP);
+    fe_mul(Q, acc.X, PP);
+    fe_mul(acc.ZZ, acc.ZZ, PP);
+    fe_mul(acc.ZZZ, acc.ZZZ, PPP);
+    xyzz_finish(X3, Y3, R, Q, PPP, acc.Y);
+    acc.X = X3;
+    acc.Y = Y3;
+    return 0;
+}
+
+// acc += (bx, by); base_identity <=> the wire x was 0 (affine.cuh:72-75)
 template <class F>
 PANDA_HD void xyzz_madd(Xyzz<F> &acc, const Fe<F> &bx, const Fe<F> &by, bool base_identity)
 {
-    typedef Bounds<F> B;
     if (base_identity) return;
     if (xyzz_is_identity(acc)) {
         xyzz_from_affine(acc, bx, by);
         return;
     }
-    Fe<F> U2, S2, P, R, PP, PPP, Q, X3, Y3;
-    fe_mul(U2, bx, acc.ZZ);
-    fe_mul(S2, by, acc.ZZZ);
-    fe_sub<F, B::XB>(P, U2, acc.X); // < PB p
-    fe_sub<F, B::YB>(R, S2, acc.Y); // < RB p
-    fe_sqr(PP, P);
-    if (fe_is_zero_2p(PP)) { // same x: P + P or P + (-P)   (projective.cuh:284-288)
-        if (fe_is_zero_mod_p(R))
-            xyzz_dbl_affine(acc, bx, by);
-        else
-            xyzz_set_identity(acc);
-        return;
-    }
-    fe_mul(PPP, P, PP);
-    fe_mul(Q, acc.X, PP);
-    xyzz_finish(X3, Y3, R, Q, PPP, acc.Y);
-    fe_mul(acc.ZZ, acc.ZZ, PP);
-    fe_mul(acc.ZZZ, acc.ZZZ, PPP);
-    acc.X = X3;
-    acc.Y = Y3;
+    const int rare = xyzz_madd_core(acc, bx, by);
+    if (rare == 1)
+        xyzz_dbl_affine(acc, bx, by);
+    else if (rare == 2)
+        xyzz_set_identity(acc);
 }
 
 // acc += q  (add-2008-s, 12M + 2S)

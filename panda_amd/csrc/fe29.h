@@ -49,6 +49,18 @@
 #define FE29_SHADOW_SHIFT()
 #endif
 
+// Multiply-accumulate into a 64-bit column.  On the device this is spelled as v_mad_u64_u32 directly: left to itself
+// hipcc sums each column in a scratch accumulator and merges it with a separate 64-bit add (v_lshl_add_u64, half
+// rate), one extra instruction per column; the explicit chain is 7-11 % faster (tools/ubench_mul.hip).  The carry
+// output of the instruction is unused (columns cannot overflow, see the bounds contract) and lands in VCC.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FE29_NO_ASM)
+#define FE29_MAC(acc, x, y) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
+#define FE29_MAC_CONST(acc, x, c) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(c) : "vcc")
+#else
+#define FE29_MAC(acc, x, y) acc += (u64)(x) * (y)
+#define FE29_MAC_CONST(acc, x, c) acc += (u64)(x) * (c)
+#endif
+
 namespace panda29 {
 
 typedef uint32_t u32;
@@ -105,16 +117,16 @@ PANDA_HD void fe_mul(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
     for (int k = 0; k < N; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) {
-            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_MAC(acc, a.l[i], b.l[k - i]);
             FE29_SHADOW_MAC(a.l[i], b.l[k - i])
         }
 #pragma unroll
         for (int i = 0; i < k; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         m[k] = ((u32)acc * F::INV) & LIMB_MASK;
-        acc += (u64)m[k] * F::P[0];
+        FE29_MAC_CONST(acc, m[k], F::P[0]);
         FE29_SHADOW_MAC(m[k], F::P[0])
         acc >>= LIMB_BITS;
         FE29_SHADOW_SHIFT()
@@ -123,12 +135,12 @@ PANDA_HD void fe_mul(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
         for (int i = k - N + 1; i < N; i++) {
-            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_MAC(acc, a.l[i], b.l[k - i]);
             FE29_SHADOW_MAC(a.l[i], b.l[k - i])
         }
 #pragma unroll
         for (int i = k - N + 1; i < N; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         out[k - N] = (u32)acc & LIMB_MASK;
@@ -156,18 +168,18 @@ PANDA_HD void fe_mul_add(Fe<F> &r, const Fe<F> &a, const Fe<F> &b, const Fe<F> &
     for (int k = 0; k < N; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) {
-            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_MAC(acc, a.l[i], b.l[k - i]);
             FE29_SHADOW_MAC(a.l[i], b.l[k - i])
-            acc += (u64)c.l[i] * d.l[k - i];
+            FE29_MAC(acc, c.l[i], d.l[k - i]);
             FE29_SHADOW_MAC(c.l[i], d.l[k - i])
         }
 #pragma unroll
         for (int i = 0; i < k; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         m[k] = ((u32)acc * F::INV) & LIMB_MASK;
-        acc += (u64)m[k] * F::P[0];
+        FE29_MAC_CONST(acc, m[k], F::P[0]);
         FE29_SHADOW_MAC(m[k], F::P[0])
         acc >>= LIMB_BITS;
         FE29_SHADOW_SHIFT()
@@ -176,14 +188,14 @@ PANDA_HD void fe_mul_add(Fe<F> &r, const Fe<F> &a, const Fe<F> &b, const Fe<F> &
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
         for (int i = k - N + 1; i < N; i++) {
-            acc += (u64)a.l[i] * b.l[k - i];
+            FE29_MAC(acc, a.l[i], b.l[k - i]);
             FE29_SHADOW_MAC(a.l[i], b.l[k - i])
-            acc += (u64)c.l[i] * d.l[k - i];
+            FE29_MAC(acc, c.l[i], d.l[k - i]);
             FE29_SHADOW_MAC(c.l[i], d.l[k - i])
         }
 #pragma unroll
         for (int i = k - N + 1; i < N; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         out[k - N] = (u32)acc & LIMB_MASK;
@@ -209,20 +221,20 @@ PANDA_HD void fe_sqr(Fe<F> &r, const Fe<F> &a)
     for (int k = 0; k < N; k++) {
 #pragma unroll
         for (int i = 0; 2 * i < k; i++) {
-            acc += (u64)a2[i] * a.l[k - i];
+            FE29_MAC(acc, a2[i], a.l[k - i]);
             FE29_SHADOW_MAC(a2[i], a.l[k - i])
         }
         if ((k & 1) == 0) {
-            acc += (u64)a.l[k / 2] * a.l[k / 2];
+            FE29_MAC(acc, a.l[k / 2], a.l[k / 2]);
             FE29_SHADOW_MAC(a.l[k / 2], a.l[k / 2])
         }
 #pragma unroll
         for (int i = 0; i < k; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         m[k] = ((u32)acc * F::INV) & LIMB_MASK;
-        acc += (u64)m[k] * F::P[0];
+        FE29_MAC_CONST(acc, m[k], F::P[0]);
         FE29_SHADOW_MAC(m[k], F::P[0])
         acc >>= LIMB_BITS;
         FE29_SHADOW_SHIFT()
@@ -231,16 +243,16 @@ PANDA_HD void fe_sqr(Fe<F> &r, const Fe<F> &a)
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
         for (int i = k - N + 1; 2 * i < k; i++) {
-            acc += (u64)a2[i] * a.l[k - i];
+            FE29_MAC(acc, a2[i], a.l[k - i]);
             FE29_SHADOW_MAC(a2[i], a.l[k - i])
         }
         if ((k & 1) == 0) {
-            acc += (u64)a.l[k / 2] * a.l[k / 2];
+            FE29_MAC(acc, a.l[k / 2], a.l[k / 2]);
             FE29_SHADOW_MAC(a.l[k / 2], a.l[k / 2])
         }
 #pragma unroll
         for (int i = k - N + 1; i < N; i++) {
-            acc += (u64)m[i] * F::P[k - i];
+            FE29_MAC_CONST(acc, m[i], F::P[k - i]);
             FE29_SHADOW_MAC(m[i], F::P[k - i])
         }
         out[k - N] = (u32)acc & LIMB_MASK;

@@ -474,18 +474,28 @@ __device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
     return lo;
 }
 
+// a converted base as it sits in HBM: 2*L words, all zero for the identity
 template <class F>
-__device__ __forceinline__ void load_base(Fe<F> &x, Fe<F> &y, bool &inf, const u32 *bases, u32 entry)
+struct PackedBase {
+    u32 w[2 * F::L];
+};
+
+template <class F>
+__device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
+{
+    load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
+}
+
+template <class F>
+__device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const PackedBase<F> &b, u32 entry)
 {
     constexpr int L = F::L;
-    u32 w[2 * L];
-    load_words<2 * L>(w, bases + (u64)(entry & 0x7fffffffu) * 2 * L);
     u32 nz = 0;
 #pragma unroll
-    for (int k = 0; k < 2 * L; k++) nz |= w[k];
+    for (int k = 0; k < 2 * L; k++) nz |= b.w[k];
     inf = (nz == 0);
-    fe_unpack(x, w);
-    fe_unpack(y, w + L);
+    fe_unpack(x, b.w);
+    fe_unpack(y, b.w + L);
     if (entry >> 31) {
         Fe<F> ny;
         fe_neg<F, 1>(ny, y); // y is canonical (< p)
@@ -498,7 +508,7 @@ __device__ __forceinline__ void load_base(Fe<F> &x, Fe<F> &y, bool &inf, const u
 // chunk may continue in the neighbouring chunks, those pieces go to `parts` and are merged by k_fixup.
 // Replaces aggerate_buckets_groups_kernel's per-bucket list walk (msm_cuda.cuh:373-409).
 template <class F>
-__global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
+__global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, unsigned log_n, unsigned NB, unsigned K,
                                                     unsigned chunks)
 {
@@ -520,9 +530,9 @@ __global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ base
     Xyzz<F> acc;
     xyzz_set_identity(acc);
 
-    Fe<F> x, y;
-    bool inf;
-    load_base<F>(x, y, inf, bases, sw[start]);
+    PackedBase<F> next_base;
+    u32 next_entry = sw[start];
+    fetch_base<F>(next_base, bases, next_entry);
     for (u32 pos = start; pos < end; pos++) {
         if (pos >= next) { // the run of bucket b ends here
             const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
@@ -533,10 +543,29 @@ __global__ void __launch_bounds__(128) k_accumulate(const u32 *__restrict__ base
                 next = ow[b + 1];
             } while (next <= pos);
         }
-        Fe<F> cx = x, cy = y;
-        const bool cinf = inf;
-        if (pos + 1 < end) load_base<F>(x, y, inf, bases, sw[pos + 1]); // prefetch the next base under this madd
-        xyzz_madd(acc, cx, cy, cinf);
+        Fe<F> cx, cy;
+        bool cinf;
+        const u32 entry = next_entry;
+        unpack_base<F>(cx, cy, cinf, next_base, entry);
+        if (pos + 1 < end) { // prefetch the next base (still packed: 16 registers) under this addition
+            next_entry = sw[pos + 1];
+            fetch_base<F>(next_base, bases, next_entry);
+        }
+        if (cinf) continue;
+        if (xyzz_is_identity(acc)) {
+            xyzz_from_affine(acc, cx, cy);
+            continue;
+        }
+        const int rare = xyzz_madd_core(acc, cx, cy);
+        if (rare) { // same x as the accumulator: reload the base instead of keeping it live through the common path
+            if (rare == 1) {
+                PackedBase<F> again;
+                fetch_base<F>(again, bases, entry);
+                unpack_base<F>(cx, cy, cinf, again, entry);
+                xyzz_dbl_affine(acc, cx, cy);
+            } else
+                xyzz_set_identity(acc);
+        }
     }
     // last run: complete only if the bucket both starts and ends inside the chunk
     const bool starts_inside = ow[b] >= start;
