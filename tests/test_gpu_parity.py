@@ -431,3 +431,14 @@ def test_committed_golden_fixtures(gm, golden_dir):
         pgm.panda_ntt_bn254_gpu_v1(gm, buf, om, c["log_n"])
         assert hashlib.sha256(buf.tobytes()).hexdigest() == c["sha256"], c["log_n"]
         assert buf[0].tobytes().hex() == c["first_hex"] and buf[-1].tobytes().hex() == c["last_hex"]
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 7, 9])
+def test_msm_tiny_sizes(gm, k):
+    """n = 1 ... 512: degenerate geometry (one tile, one chunk, a single partition)."""
+    n = 1 << k
+    for cid in (0, 1):
+        bases = po.gen_bases(cid, 900 + k, n)
+        scalars = po.gen_scalars(po.FR_OF[cid], 950 + k, n)
+        out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
+        assert (affine_of(cid, out) == po.to_affine(cid, po.msm_naive(cid, bases, scalars))).all()
