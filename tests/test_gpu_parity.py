@@ -380,11 +380,12 @@ def test_cpp_gpu_manager_mirror():
     """The C++ mirror of the reference's Rust gpu_manager + its integration test binary (panda_amd/csrc/tests/manager_test.cpp,
     the counterpart of tests/test.rs): device MSM vs the CPU entry point, cached variants, NTT round trips."""
     import subprocess
-    exe = os.path.join(os.path.dirname(ffi.LIB_PATH), "tests", "manager_test")
-    assert os.path.exists(exe), "build it with make -C panda_amd/csrc"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "manager_test: all ok" in r.stdout
+    for name in ("manager_test", "manager_test_static"):  # shared object, and the static archive build.rs links
+        exe = os.path.join(os.path.dirname(ffi.LIB_PATH), "tests", name)
+        assert os.path.exists(exe), "build it with make -C panda_amd/csrc"
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "manager_test: all ok" in r.stdout
 
 
 @pytest.mark.parametrize("cid,k,coord", [(0, 24, pgm.JACOBIAN), (1, 24, pgm.PROJECTIVE), (0, 26, pgm.JACOBIAN)])
