@@ -243,16 +243,21 @@ def ntt_figure(lib, ffi, torch, dev, pstream, log_n: int = 24, reps: int = 5) ->
     omega = _root_of_unity_host(lib, ffi, log_n)
     flag = C.c_uint(0)
     cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
-    times = []
-    for r in range(reps + 1):
-        t = time.perf_counter()
-        ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
-        if r:
-            times.append(time.perf_counter() - t)
-    times.sort()
-    med = times[len(times) // 2]
-    gbs = BYTES_PER_NTT_ELEM * n / med / 1e9
-    return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / med, "unit": "elements/s", "ms": med * 1e3,
+    def timed(fn):
+        ts = []
+        for r in range(reps + 1):
+            t = time.perf_counter()
+            ffi.check(fn(cfg), "ntt")
+            if r:
+                ts.append(time.perf_counter() - t)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    fwd = timed(lib.panda_ntt_execute_bn254_v1)
+    inv = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
+    gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
+    return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3,
+            "inverse_ms": inv * 1e3, "forward_plus_inverse_elements_per_s": n / (fwd + inv),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 

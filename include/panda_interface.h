@@ -158,6 +158,9 @@ const char *panda_msm_phase_name(unsigned phase);
 /* Inverse transform: runs the forward passes with omega^-1 and fuses the n^-1 scaling into the last pass.
  * d_omega is the FORWARD root (host pointer), as for _v1. */
 panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exec_cfg);
+/* The same transforms over the BLS12-377 scalar field (README.md:36: "easy to encapsulate ... BLS12-377 later") */
+panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1 exec_cfg);
 
 /* Multi-GPU, one process per GPU.  The exchange itself is the caller's (RCCL through
  * torch.distributed or ncclAllGather): these are the per-rank halves either side of it.

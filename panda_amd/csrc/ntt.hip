@@ -33,11 +33,9 @@ using namespace panda29;
 
 namespace {
 
-typedef Bn254Fr Fr;
-constexpr int NL = Fr::N;       // 9 limbs
+constexpr int NL = 9;           // limbs of every supported scalar field (BN254 Fr, BLS12-377 Fr)
 constexpr int TW_STRIDE = 12;   // table entries padded to 48 B for 16-byte loads
 constexpr int TILE = 1024;      // elements per workgroup
-constexpr long long LIM = Fr::HEADROOM * 9 / 10;
 
 struct PowBase {
     u32 pw[16][NL]; // base^(2^j), canonical internal form
@@ -46,6 +44,7 @@ struct PowBase {
 };
 
 // out[t] = base^t (* scale), canonical, t < count
+template <class Fr>
 __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u32 *__restrict__ out)
 {
     unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,6 +71,7 @@ __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u
     for (int i = NL; i < TW_STRIDE; i++) dst[i] = 0;
 }
 
+template <class Fr>
 __device__ __forceinline__ void load_tw(Fe<Fr> &r, const u32 *__restrict__ tab, unsigned idx)
 {
     const uint4 *s = reinterpret_cast<const uint4 *>(tab + (size_t)idx * TW_STRIDE);
@@ -81,6 +81,7 @@ __device__ __forceinline__ void load_tw(Fe<Fr> &r, const u32 *__restrict__ tab, 
     r.l[8] = c.x;
 }
 
+template <class Fr>
 __device__ __forceinline__ void load_elem(Fe<Fr> &v, const u32 *__restrict__ src)
 {
     const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
@@ -90,6 +91,7 @@ __device__ __forceinline__ void load_elem(Fe<Fr> &v, const u32 *__restrict__ src
 }
 
 // canonical element -> 32 bytes
+template <class Fr>
 __device__ __forceinline__ void store_elem(u32 *__restrict__ dst, const Fe<Fr> &v)
 {
     u32 w8[8];
@@ -110,12 +112,14 @@ struct Planes {
     static constexpr int STRIDE = COUNT + COUNT / 32;
     u32 *base;
     __device__ __forceinline__ static unsigned pad(unsigned e) { return e + (e >> 5); }
+    template <class Fr>
     __device__ __forceinline__ void load(Fe<Fr> &r, unsigned e) const
     {
         const unsigned p = pad(e);
 #pragma unroll
         for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + p];
     }
+    template <class Fr>
     __device__ __forceinline__ void store(const Fe<Fr> &r, unsigned e) const
     {
         const unsigned p = pad(e);
@@ -127,11 +131,12 @@ typedef Planes<TILE> TilePlanes;
 typedef Planes<128> TwiddlePlanes;
 
 // Rounds RND..DEG-1 of the radix-2^DEG sub-transform; BC = bound (units of p) of every element in LDS.
-template <int DEG, int RND, int BC>
+template <class Fr, int DEG, int RND, int BC>
 struct Rounds {
+    static constexpr long long LIM = Fr::HEADROOM * 9 / 10;
     static constexpr bool REDUCE = (2 * BC + 1) >= LIM; // (a - b + (BC+1) p) * twiddle must stay below 0.9 R p
     static constexpr int B0 = REDUCE ? 1 : BC;
-    static constexpr int FINAL = Rounds<DEG, RND + 1, 2 * B0 + 1>::FINAL;
+    static constexpr int FINAL = Rounds<Fr, DEG, RND + 1, 2 * B0 + 1>::FINAL;
     __device__ __forceinline__ static void run(const TilePlanes &u, const TwiddlePlanes &pq, unsigned blk_base, unsigned t)
     {
         constexpr unsigned R = 1u << DEG;
@@ -155,11 +160,11 @@ struct Rounds {
         u.store(s, blk_base + i0);
         u.store(d, blk_base + i1);
         __syncthreads();
-        Rounds<DEG, RND + 1, 2 * B0 + 1>::run(u, pq, blk_base, t);
+        Rounds<Fr, DEG, RND + 1, 2 * B0 + 1>::run(u, pq, blk_base, t);
     }
 };
-template <int DEG, int BC>
-struct Rounds<DEG, DEG, BC> {
+template <class Fr, int DEG, int BC>
+struct Rounds<Fr, DEG, DEG, BC> {
     static constexpr int FINAL = BC;
     __device__ __forceinline__ static void run(const TilePlanes &, const TwiddlePlanes &, unsigned, unsigned) {}
 };
@@ -178,7 +183,7 @@ struct PassArgs {
     unsigned strided_out; // write output i of sub-transform blk to blk + i*S (the input's own layout)
 };
 
-template <int DEG>
+template <class Fr, int DEG>
 __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
 {
     constexpr unsigned R = 1u << DEG;
@@ -227,12 +232,12 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
     const bool active = tid < (TE >> 1);
     // every thread passes the DEG barriers of the rounds; threads beyond a short tile only wait
     if (active)
-        Rounds<DEG, 0, 2>::run(u, pq, sub * R, t);
+        Rounds<Fr, DEG, 0, 2>::run(u, pq, sub * R, t);
     else
         for (int r = 0; r < DEG; r++) __syncthreads();
 
-    constexpr int FB = Rounds<DEG, 0, 2>::FINAL;
-    static_assert(FB < 256, "final bound must fit fe_reduce_small");
+    constexpr int FB = Rounds<Fr, DEG, 0, 2>::FINAL;
+    static_assert(FB < 512, "final bound must fit fe_reduce_small (values below 2^9 p)");
     for (unsigned e = tid; e < TE; e += 512) {
         unsigned b, i;
         size_t dst_index;
@@ -258,6 +263,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
 }
 
 // x[i] *= ta[i & 0xffff] * tb[i >> 16]   (the inter-slab twiddle w^(r k2) of the multi-GPU transform)
+template <class Fr>
 __global__ void __launch_bounds__(256) k_slab_twiddle(u32 *__restrict__ x, const u32 *__restrict__ ta, const u32 *__restrict__ tb, unsigned count)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +291,7 @@ const size_t SZ_TA = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
 const size_t SZ_TB = panda::align256((size_t)(1u << 12) * TW_STRIDE * 4);
 const size_t SZ_PQ = panda::align256((size_t)128 * TW_STRIDE * 4);
 
+template <class Fr>
 void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
 {
     Fe<Fr> cur = base;
@@ -298,24 +305,26 @@ void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
     for (int i = 0; i < NL; i++) pb.scale[i] = scale ? scale->l[i] : 0;
 }
 
+template <class Fr>
 void build_table(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, unsigned count, u32 *d_out)
 {
     PowBase pb;
-    fill_pow_base(pb, base, scale);
-    hipLaunchKernelGGL(k_pow_table, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, d_out);
+    fill_pow_base<Fr>(pb, base, scale);
+    hipLaunchKernelGGL(k_pow_table<Fr>, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, d_out);
 }
 
+template <class Fr>
 void launch_pass(unsigned deg, const PassArgs &a, unsigned tiles, hipStream_t s)
 {
     switch (deg) {
-    case 1: hipLaunchKernelGGL(k_ntt_pass<1>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_ntt_pass<2>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_ntt_pass<3>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_ntt_pass<4>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(k_ntt_pass<5>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(k_ntt_pass<6>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(k_ntt_pass<7>, dim3(tiles), dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL(k_ntt_pass<8>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((k_ntt_pass<Fr, 1>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_ntt_pass<Fr, 2>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_ntt_pass<Fr, 3>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_ntt_pass<Fr, 4>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_ntt_pass<Fr, 5>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((k_ntt_pass<Fr, 6>), dim3(tiles), dim3(512), 0, s, a); break;
+    case 7: hipLaunchKernelGGL((k_ntt_pass<Fr, 7>), dim3(tiles), dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_ntt_pass<Fr, 8>), dim3(tiles), dim3(512), 0, s, a); break;
     }
 }
 
@@ -334,6 +343,7 @@ hipError_t order_after_null_stream(hipStream_t stream)
 // All passes of one local transform of size 2^log_n with root `omega` (internal form).  `scale`, when given,
 // multiplies every output (folded into the last pass's twiddles).  Leaves the result in src when *passes_out
 // is even, in dst when odd; enqueues only.
+template <class Fr>
 hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
                       unsigned *passes_out)
 {
@@ -361,20 +371,20 @@ hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u
         a.strided_out = 0;
         Fe<Fr> base;
         fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
-        build_table(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
+        build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
         if (log_p != 0) {
             fe_pow_u64(base, omega, n >> log_p >> deg);
-            build_table(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
+            build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
             if (mbits > 16) {
                 Fe<Fr> base_b;
                 fe_pow_u64(base_b, base, (u64)1 << 16);
-                build_table(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
+                build_table<Fr>(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
             }
         } else if (a.force_tw) {
             fe_one(base);
-            build_table(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
+            build_table<Fr>(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
         }
-        launch_pass(deg, a, (unsigned)(n / a.tile_elems), stream);
+        launch_pass<Fr>(deg, a, (unsigned)(n / a.tile_elems), stream);
         PANDA_TRY(hipGetLastError());
         const u32 *tmp = dst;
         dst = const_cast<u32 *>(src);
@@ -386,6 +396,7 @@ hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u
     return hipSuccess;
 }
 
+template <class Fr>
 void inverse_parameters(Fe<Fr> &omega, Fe<Fr> &scale, u64 n)
 {
     Fe<Fr> oi, nfe;
@@ -396,23 +407,25 @@ void inverse_parameters(Fe<Fr> &omega, Fe<Fr> &scale, u64 n)
     fe_reduce_once(scale);
 }
 
+template <class Fr>
 hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omega_wire, unsigned log_n, unsigned *flag, bool inverse)
 {
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
     Fe<Fr> omega, scale;
     fe_from_wire(omega, omega_wire);
-    if (inverse) inverse_parameters(omega, scale, (u64)1 << log_n);
+    if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
     panda::Arena &arena = panda::thread_arena();
     PANDA_TRY(arena.reserve(4 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
     unsigned passes = 0;
-    PANDA_TRY(ntt_passes(stream, arena, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes));
+    PANDA_TRY(ntt_passes<Fr>(stream, arena, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
     return hipSuccess;
 }
 
 // multi-GPU step 1: local transform of the rank's decimated slab + the inter-slab twiddle w^(rank * k2)
+template <class Fr>
 hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
@@ -426,19 +439,19 @@ hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
     panda::Arena &arena = panda::thread_arena();
     PANDA_TRY(arena.reserve(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
     unsigned passes = 0;
-    PANDA_TRY(ntt_passes(stream, arena, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes));
+    PANDA_TRY(ntt_passes<Fr>(stream, arena, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes));
     u32 *res = (passes & 1u) ? (u32 *)cfg.d_scratch : (u32 *)cfg.d_slab;
     if (cfg.rank != 0) {
         u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB);
         if (!d_ta || !d_tb) return hipErrorOutOfMemory;
         Fe<Fr> base, base_b;
         fe_pow_u64(base, omega, cfg.rank);
-        build_table(stream, base, nullptr, (unsigned)std::min<u64>(m, 1u << 16), d_ta);
+        build_table<Fr>(stream, base, nullptr, (unsigned)std::min<u64>(m, 1u << 16), d_ta);
         if (log_m > 16) {
             fe_pow_u64(base_b, base, (u64)1 << 16);
-            build_table(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
+            build_table<Fr>(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
         }
-        hipLaunchKernelGGL(k_slab_twiddle, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, res, d_ta, d_tb, (unsigned)m);
+        hipLaunchKernelGGL(k_slab_twiddle<Fr>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, res, d_ta, d_tb, (unsigned)m);
         PANDA_TRY(hipGetLastError());
     }
     if (cfg.flag) *(unsigned *)cfg.flag = passes & 1u;
@@ -447,6 +460,7 @@ hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
 }
 
 // multi-GPU step 2: after the all-to-all the slab holds [j1][k2'] (G x m/G); transforms of size G down j1
+template <class Fr>
 hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < 2 * cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
@@ -463,7 +477,7 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
         u32 *d_pq = (u32 *)arena.take(SZ_PQ);
         if (!d_pq) return hipErrorOutOfMemory;
         fe_pow_u64(base, omega, m); // w^m has order G
-        build_table(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
+        build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
         PassArgs a{};
         a.x = (const u32 *)cfg.d_slab;
         a.y = (u32 *)cfg.d_scratch;
@@ -475,7 +489,7 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
         a.force_tw = 0;
         a.tile_elems = (unsigned)std::min<u64>(TILE, m);
         a.strided_out = 1;
-        launch_pass(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
+        launch_pass<Fr>(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
         PANDA_TRY(hipGetLastError());
         out_in_scratch = 1;
     }
@@ -505,24 +519,37 @@ panda_error panda_ntt_execute_bn254(panda_ntt_configuration cfg)
         if (!g_omega_set) return panda_error_invalid_value;
         memcpy(omega, g_omega_wire, sizeof(omega));
     }
-    return static_cast<panda_error>(ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, omega, cfg.log_n, (unsigned *)cfg.flag, false));
+    return static_cast<panda_error>(ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, omega, cfg.log_n, (unsigned *)cfg.flag, false));
 }
 
 panda_error panda_ntt_execute_bn254_v1(const panda_ntt_configuration_v1 cfg)
 {
     return static_cast<panda_error>(
-        ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false));
+        ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false));
 }
 
 panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 cfg)
 {
     return static_cast<panda_error>(
-        ntt_run(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+        ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
 }
 
-panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1(cfg)); }
+panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg)); }
 
-panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2(cfg)); }
+panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg)); }
+
+// BLS12-377 Fr (two-adicity 47): same kernels, other field parameters
+panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false));
+}
+
+panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+}
 
 panda_error panda_ntt_tear_down(void)
 {

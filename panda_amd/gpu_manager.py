@@ -309,6 +309,12 @@ def panda_ntt_bn254_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_
     return _ntt(gm, scalars, log_n, ffi.load().panda_ntt_execute_bn254_v1, omega)
 
 
+def panda_ntt_bls12_377_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:
+    """Additive: the same staging for the BLS12-377 scalar field."""
+    lib = ffi.load()
+    return _ntt(gm, scalars, log_n, lib.panda_ntt_execute_bls12_377_inverse if inverse else lib.panda_ntt_execute_bls12_377_v1, omega)
+
+
 def panda_intt_bn254_gpu(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int) -> int:
     """Additive: inverse transform with the n^-1 scaling fused (panda_ntt_execute_bn254_inverse)."""
     return _ntt(gm, scalars, log_n, ffi.load().panda_ntt_execute_bn254_inverse, omega)

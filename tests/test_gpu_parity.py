@@ -443,3 +443,16 @@ def test_msm_tiny_sizes(gm, k):
         scalars = po.gen_scalars(po.FR_OF[cid], 950 + k, n)
         out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
         assert (affine_of(cid, out) == po.to_affine(cid, po.msm_naive(cid, bases, scalars))).all()
+
+
+@pytest.mark.parametrize("log_n", [3, 8, 11, 17])
+def test_ntt_bls12_377_fr(gm, log_n):
+    """The NTT kernels instantiated for the BLS12-377 scalar field (additive entry points)."""
+    fid = po.F_BLS377_FR
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 4000 + log_n, 1 << log_n)
+    buf = x.copy()
+    pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n)
+    assert (buf == po.ntt(fid, x, om, log_n)).all()
+    pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n, inverse=True)
+    assert (buf == x).all()
