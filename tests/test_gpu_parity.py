@@ -456,3 +456,37 @@ def test_ntt_bls12_377_fr(gm, log_n):
     assert (buf == po.ntt(fid, x, om, log_n)).all()
     pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n, inverse=True)
     assert (buf == x).all()
+
+
+def test_msm_and_ntt_from_two_host_threads():
+    """The library is callable from any host thread (SURVEY 8b threading): scratch is per thread, MSM has no global state."""
+    import threading
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            g = pgm.PandaGpuManager(0)
+            for rep in range(3):
+                n = 1 << 13
+                bases = po.gen_bases(0, 7000 + tid, n)
+                scalars = po.gen_scalars(po.F_BN254_FR, 7100 + tid * 10 + rep, n)
+                out = pgm.panda_msm_bn254_gpu(g, scalars, bases)
+                results[(tid, rep)] = (affine_of(0, out), po.expected_from_linearity(0, 7000 + tid, scalars))
+                om = po.root_of_unity(po.F_BN254_FR, 12)
+                x = po.gen_scalars(po.F_BN254_FR, 7200 + tid, 1 << 12)
+                buf = x.copy()
+                pgm.panda_ntt_bn254_gpu_v1(g, buf, om, 12)
+                results[(tid, rep, "ntt")] = (buf, po.ntt(po.F_BN254_FR, x, om, 12))
+            g.deinit()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12
+    for got, want in results.values():
+        assert (got == want).all()
