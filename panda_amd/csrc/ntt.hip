@@ -340,12 +340,64 @@ hipError_t order_after_null_stream(hipStream_t stream)
     return hipSuccess;
 }
 
+// Twiddle tables of the last transform run by this host thread, kept on the device: a prover transforms many
+// polynomials with the same root, and rebuilding three small tables per pass costs ~0.1 ms of launches per call.
+struct TwiddleCache {
+    void *base = nullptr;
+    size_t capacity = 0, used = 0;
+    int device = -1;
+    bool valid = false;
+    u32 key[12] = {0};
+    hipError_t ensure(size_t bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (base && (dev != device || bytes > capacity)) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(base);
+            base = nullptr;
+            valid = false;
+        }
+        if (!base) {
+            e = hipMalloc(&base, bytes);
+            if (e != hipSuccess) return e;
+            capacity = bytes;
+            device = dev;
+            valid = false;
+        }
+        used = 0;
+        return hipSuccess;
+    }
+    void *take(size_t bytes)
+    {
+        size_t off = (used + 255) & ~(size_t)255;
+        if (off + bytes > capacity) return nullptr;
+        used = off + bytes;
+        return (char *)base + off;
+    }
+    hipError_t release()
+    {
+        hipError_t e = hipSuccess;
+        if (base) {
+            (void)hipDeviceSynchronize();
+            e = hipFree(base);
+        }
+        base = nullptr;
+        capacity = used = 0;
+        valid = false;
+        return e;
+    }
+};
+thread_local TwiddleCache g_twiddles;
+
 // All passes of one local transform of size 2^log_n with root `omega` (internal form).  `scale`, when given,
 // multiplies every output (folded into the last pass's twiddles).  Leaves the result in src when *passes_out
 // is even, in dst when odd; enqueues only.
-template <class Fr>
-hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
-                      unsigned *passes_out)
+// `build` = false reuses the tables already sitting in `arena` (same carve order).
+template <class Fr, class Alloc>
+hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
+                      unsigned *passes_out, bool build = true)
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
@@ -370,19 +422,21 @@ hipError_t ntt_passes(hipStream_t stream, panda::Arena &arena, const u32 *src, u
         a.force_tw = (scale && last) ? 1 : 0;
         a.strided_out = 0;
         Fe<Fr> base;
-        fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
-        build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
-        if (log_p != 0) {
-            fe_pow_u64(base, omega, n >> log_p >> deg);
-            build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
-            if (mbits > 16) {
-                Fe<Fr> base_b;
-                fe_pow_u64(base_b, base, (u64)1 << 16);
-                build_table<Fr>(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
+        if (build) {
+            fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
+            build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
+            if (log_p != 0) {
+                fe_pow_u64(base, omega, n >> log_p >> deg);
+                build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
+                if (mbits > 16) {
+                    Fe<Fr> base_b;
+                    fe_pow_u64(base_b, base, (u64)1 << 16);
+                    build_table<Fr>(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
+                }
+            } else if (a.force_tw) {
+                fe_one(base);
+                build_table<Fr>(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
             }
-        } else if (a.force_tw) {
-            fe_one(base);
-            build_table<Fr>(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
         }
         launch_pass<Fr>(deg, a, (unsigned)(n / a.tile_elems), stream);
         PANDA_TRY(hipGetLastError());
@@ -412,15 +466,28 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
 {
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
+    TwiddleCache &tw = g_twiddles;
+    u32 key[12] = {Fr::PW[0] ^ Fr::PW[7], log_n, inverse ? 1u : 0u, 0};
+    for (int i = 0; i < 8; i++) key[3 + i] = omega_wire[i];
+    int dev = -1;
+    PANDA_TRY(hipGetDevice(&dev));
+    const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
     Fe<Fr> omega, scale;
-    fe_from_wire(omega, omega_wire);
-    if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-    panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(4 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    fe_zero(omega);
+    fe_zero(scale);
+    if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
+        fe_from_wire(omega, omega_wire);
+        if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
+        PANDA_TRY(tw.ensure(4 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    } else
+        tw.used = 0;
+    tw.valid = false;
     unsigned passes = 0;
-    PANDA_TRY(ntt_passes<Fr>(stream, arena, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes));
+    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
+    memcpy(tw.key, key, sizeof(key));
+    tw.valid = true; // only after the tables are known to be complete
     return hipSuccess;
 }
 
@@ -555,6 +622,7 @@ panda_error panda_ntt_tear_down(void)
 {
     std::lock_guard<std::mutex> lock(g_omega_mutex);
     g_omega_set = false;
+    (void)g_twiddles.release();
     return static_cast<panda_error>(panda::release_thread_arena());
 }
 

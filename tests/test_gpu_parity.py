@@ -490,3 +490,25 @@ def test_msm_and_ntt_from_two_host_threads():
     assert len(results) == 12
     for got, want in results.values():
         assert (got == want).all()
+
+
+def test_ntt_twiddle_cache_reuse_and_invalidation(gm):
+    """Twiddle tables are cached per host thread between calls: same root twice (hit), then another primitive root of the
+    same size, then the inverse with the first root (misses) -- every result must still match the oracle."""
+    fid, log_n = po.F_BN254_FR, 13
+    c = pyref.CURVES[0]
+    om = po.root_of_unity(fid, log_n)
+    w = pyref.decode_scalar(c, om)
+    om3 = pyref.int_to_limbs(pow(w, 3, c.r) * c.Rr % c.r, 8)  # another primitive 2^13-th root
+    for seed, root in ((1, om), (2, om), (3, om3), (4, om), (5, om3), (6, om3)):
+        x = po.gen_scalars(fid, 8000 + seed, 1 << log_n)
+        buf = x.copy()
+        pgm.panda_ntt_bn254_gpu_v1(gm, buf, root, log_n)
+        assert (buf == po.ntt(fid, x, root, log_n)).all(), seed
+        if seed in (2, 5):
+            pgm.panda_intt_bn254_gpu(gm, buf, root, log_n)
+            assert (buf == x).all()
+            pgm.panda_intt_bn254_gpu(gm, buf, root, log_n)  # inverse again on a hit: x scaled through the inverse transform
+            om_inv = po.f_vec(fid, po.OP_INV, root[None])[0]
+            n_inv = pyref.int_to_limbs(pow(1 << log_n, -1, c.r) * c.Rr % c.r, 8)
+            assert (buf == po.f_scale(fid, po.ntt(fid, x, om_inv, log_n), n_inv)).all()
