@@ -148,6 +148,12 @@ panda_error panda_msm_setup_bls12_377(void);
 panda_error panda_msm_execute_bls12_377(const panda_msm_configuration exec_cfg);
 panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration exec_cfg);
 
+/* Cached bases (README.md "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): registering a device buffer
+ * of 2^log_n affine bases lets the library keep its radix-converted copy between calls instead of re-deriving it in every
+ * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377. */
+panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream);
+panda_error panda_msm_unregister_bases(const void *d_bases);
+
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
 panda_error panda_msm_set_window_bits(unsigned window_bits);
 /* per-phase device times of the last MSM on this thread, milliseconds; names via panda_msm_phase_name */

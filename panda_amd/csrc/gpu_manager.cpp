@@ -102,6 +102,15 @@ PandaGpuError PandaGpuManager::init_all(size_t device_id, PandaGpuManagerInitUni
     return PandaGpuError::Ok;
 }
 
+PandaGpuError PandaGpuManager::register_cached_bases(size_t index, uint32_t log_n)
+{
+    void *d = get_params_bases_ptr_mut(index);
+    if (!d) return PandaGpuError::BasesIndexErr;
+    if (panda_msm_register_bases(0, d, log_n, exec_stream_) != 0) return PandaGpuError::CreateContextError;
+    registered_bases.push_back(d);
+    return PandaGpuError::Ok;
+}
+
 PandaGpuError PandaGpuManager::wait_h2d() const
 {
     Event ev;
@@ -129,6 +138,9 @@ PandaGpuError PandaGpuManager::sync() const
 
 PandaGpuError PandaGpuManager::deinit()
 {
+    for (void *p : registered_bases)
+        if (panda_msm_unregister_bases(p) != 0) return PandaGpuError::DestroyContextErr;
+    registered_bases.clear();
     for (void *p : d_bases)
         if (panda_free(p) != 0) return PandaGpuError::DestroyContextErr;
     for (void *p : d_scalars)

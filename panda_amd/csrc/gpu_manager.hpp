@@ -83,6 +83,8 @@ class PandaGpuManager {
     static PandaGpuError init_msm_cached_bases(Bytes bases, void **d_ptr);               // wrapper.rs:154-169
     static PandaGpuError init_msm_cached_scalars(Bytes scalars, void **d_ptr);           // wrapper.rs:171-186
     static PandaGpuError init_ntt(Bytes omega);                                          // wrapper.rs:199-210
+    // additive: let the library keep the radix-converted copy of cached base set `index` (2^log_n points) between calls
+    PandaGpuError register_cached_bases(size_t index, uint32_t log_n);
 
     void set_config(panda_msm_result_coordinate_type t) { msm_result_coordinate_type_ = t; } // wrapper.rs:212-214
     panda_mem_pool get_mem_pool() const { return mem_pool_; }
@@ -102,6 +104,7 @@ class PandaGpuManager {
 
     std::vector<void *> d_bases, d_scalars; // pub in the reference (wrapper.rs:15-17)
     std::vector<size_t> scalars_len;
+    std::vector<void *> registered_bases;
 
   private:
     size_t device_id_ = 0;

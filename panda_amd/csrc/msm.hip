@@ -725,6 +725,28 @@ __global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in,
 // ------------------------------------------------------------------------------- host side
 
 thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
+
+// Cached bases (README "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): a caller that keeps a base
+// set on the device for many MSMs may register it; the radix conversion k_convert_bases would repeat on every call is
+// then done once and kept next to it.  The caller promises not to modify a registered buffer until it is unregistered.
+struct RegisteredBases {
+    const void *wire; // the caller's device pointer (the key)
+    void *converted;
+    unsigned log_n, curve;
+    int device;
+};
+std::mutex g_registry_mutex;
+std::vector<RegisteredBases> g_registry;
+
+const void *lookup_registered(const void *wire, unsigned log_n, unsigned curve)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (const auto &r : g_registry)
+        if (r.wire == wire && r.log_n == log_n && r.curve == curve && r.device == dev) return r.converted;
+    return nullptr;
+}
 unsigned g_window_override = 0;
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
@@ -852,7 +874,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
 
     PANDA_TRY(mark(0));
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
+    const u32 *registered = (const u32 *)lookup_registered(cfg.bases, log_n, Fq::N == 9 ? 0u : 1u);
+    if (registered)
+        d_bases = const_cast<u32 *>(registered); // converted once at registration
+    else
+        hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
     hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, plan);
     PANDA_TRY(mark(1));
     hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
@@ -925,6 +951,56 @@ panda_error panda_msm_setup_bn254(void) { return panda_success; }
 panda_error panda_msm_setup_bls12_377(void) { return panda_success; }
 
 panda_error panda_msm_tear_down(void) { return static_cast<panda_error>(panda::release_thread_arena()); }
+
+panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream)
+{
+    if (curve > 1 || !d_bases || log_n > 26) return panda_error_invalid_value;
+    if (lookup_registered(d_bases, log_n, curve)) return panda_success;
+    const u64 n = (u64)1 << log_n;
+    const size_t bytes = n * (curve == 0 ? 64 : 96);
+    RegisteredBases r{d_bases, nullptr, log_n, curve, -1};
+    hipError_t e = hipGetDevice(&r.device);
+    if (e == hipSuccess) e = hipMalloc(&r.converted, bytes);
+    if (e != hipSuccess) return static_cast<panda_error>(e);
+    hipStream_t s = static_cast<hipStream_t>(stream.handle);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (curve == 0)
+        hipLaunchKernelGGL(k_convert_bases<Bn254Fq>, dim3(blocks), dim3(256), 0, s, (const u32 *)d_bases, (u32 *)r.converted, n);
+    else
+        hipLaunchKernelGGL(k_convert_bases<Bls377Fq>, dim3(blocks), dim3(256), 0, s, (const u32 *)d_bases, (u32 *)r.converted, n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipFree(r.converted);
+        return static_cast<panda_error>(e);
+    }
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry.push_back(r);
+    return panda_success;
+}
+
+panda_error panda_msm_unregister_bases(const void *d_bases)
+{
+    std::vector<void *> to_free;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        for (size_t i = 0; i < g_registry.size();) {
+            if (g_registry[i].wire == d_bases) {
+                to_free.push_back(g_registry[i].converted);
+                g_registry.erase(g_registry.begin() + i);
+            } else
+                i++;
+        }
+    }
+    if (to_free.empty()) return panda_error_invalid_value;
+    (void)hipDeviceSynchronize();
+    hipError_t e = hipSuccess;
+    for (void *p : to_free) {
+        hipError_t f = hipFree(p);
+        if (f != hipSuccess) e = f;
+    }
+    return static_cast<panda_error>(e);
+}
 
 panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute<CurveBn254>(cfg)); }
 

@@ -105,6 +105,14 @@ class PandaGpuManager:
         self.d_scalars: list[int] = []
         self.scalars_len: list[int] = []
         self.msm_result_coordinate_type = JACOBIAN
+        self._bases_bytes: dict[int, int] = {}
+        self._registered: list[int] = []
+
+    def add_cached_bases(self, bases) -> int:
+        """init_msm_cached_bases + push onto d_bases (what callers of the reference do by hand); returns the index."""
+        self.d_bases.append(self.init_msm_cached_bases(bases))
+        self._bases_bytes[len(self.d_bases) - 1] = _as_bytes(bases).size
+        return len(self.d_bases) - 1
 
     @classmethod
     def init_all(cls, device_id, bases=None, omega=None):  # wrapper.rs:55-113
@@ -134,6 +142,17 @@ class PandaGpuManager:
         return d.value
 
     init_msm_cached_scalars = init_msm_cached_bases  # wrapper.rs:171-186: same staging
+
+    def register_cached_bases(self, index: int, curve: int = 0) -> None:
+        """Additive: let the library keep the radix-converted copy of cached base set `index` between calls
+        (panda_msm_register_bases).  The buffer must stay unmodified until deinit()."""
+        d = self.get_params_bases_ptr_mut(index)
+        if d is None:
+            raise PandaGpuError("BasesIndexErr")
+        nbytes = self._bases_bytes[index]
+        log_n = log_2(nbytes // _POINT_BYTES[curve])
+        ffi.check(ffi.load().panda_msm_register_bases(curve, C.c_void_p(d), log_n, self.exec_stream.raw), "CreateContextError")
+        self._registered.append(d)
 
     @classmethod
     def init_msm(cls, bases_list) -> list[int]:  # wrapper.rs:122-152
@@ -171,6 +190,9 @@ class PandaGpuManager:
 
     def deinit(self):  # wrapper.rs:297-312
         lib = ffi.load()
+        for d in self._registered:
+            ffi.check(lib.panda_msm_unregister_bases(C.c_void_p(d)), "DestroyContextErr")
+        self._registered = []
         for d in self.d_bases + self.d_scalars:
             ffi.check(lib.panda_free(C.c_void_p(d)), "DestroyContextErr")
         self.d_bases, self.d_scalars, self.scalars_len = [], [], []

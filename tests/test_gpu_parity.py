@@ -512,3 +512,21 @@ def test_ntt_twiddle_cache_reuse_and_invalidation(gm):
             om_inv = po.f_vec(fid, po.OP_INV, root[None])[0]
             n_inv = pyref.int_to_limbs(pow(1 << log_n, -1, c.r) * c.Rr % c.r, 8)
             assert (buf == po.f_scale(fid, po.ntt(fid, x, om_inv, log_n), n_inv)).all()
+
+
+def test_msm_registered_cached_bases(gm):
+    """panda_msm_register_bases: same answers with the conversion cached; a different buffer is unaffected; unregister works."""
+    lib = ffi.load()
+    n = 1 << 13
+    for cid in (0, 1):
+        bases = po.gen_bases(cid, 9100 + cid, n)
+        other = po.gen_bases(cid, 9200 + cid, n)
+        idx = gm.add_cached_bases(bases)
+        gm.register_cached_bases(idx, curve=cid)
+        for rep in range(3):
+            scalars = po.gen_scalars(po.FR_OF[cid], 9300 + rep, n)
+            out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=cid)
+            assert (affine_of(cid, out) == po.expected_from_linearity(cid, 9100 + cid, scalars)).all()
+            out2 = pgm.panda_msm_bn254_gpu(gm, scalars, other, curve=cid)  # unregistered path still converts per call
+            assert (affine_of(cid, out2) == po.expected_from_linearity(cid, 9200 + cid, scalars)).all()
+    assert lib.panda_msm_unregister_bases(C.c_void_p(12345)) != 0
