@@ -153,9 +153,19 @@ panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration exec_
  * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377. */
 panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream);
 panda_error panda_msm_unregister_bases(const void *d_bases);
+/* Cached bases with precomputed window tables (the lookup-table idea the reference left as a stub, msm_host.cuh:248-265):
+ * besides the converted copy the library keeps 2^lo[k] * P for every window k (W tables of 2^log_n affine rows, built once,
+ * about W * 64 B per BN254 point).  Every window then shares one bucket space, which permits windows of up to 23 bits and
+ * removes the per-window reductions.  window_bits 0 = built-in policy.  Results are the same group element as without tables.
+ * Undone by panda_msm_unregister_bases. */
+panda_error panda_msm_precompute_bases(unsigned curve, const void *d_bases, unsigned log_n, unsigned window_bits, panda_stream stream);
+/* what is registered for d_bases: number of tables (1 = converted copy only), window bits (0 if none), device bytes held */
+panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, unsigned *window_bits, size_t *bytes);
 
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
 panda_error panda_msm_set_window_bits(unsigned window_bits);
+/* buckets per thread in the bucket-reduction kernel, for experiments: 0 = built-in policy */
+panda_error panda_msm_set_reduce_group(unsigned group);
 /* per-phase device times of the last MSM on this thread, milliseconds; names via panda_msm_phase_name */
 #define PANDA_MSM_PHASES 8
 panda_error panda_msm_last_phase_ms(float *ms /* PANDA_MSM_PHASES floats */);

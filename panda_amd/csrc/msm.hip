@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "curve29.h"
+#include "msm_sort.h"
 #include "panda_internal.h"
 
 using namespace panda29;
@@ -90,8 +91,6 @@ hipError_t release_thread_arena() { return thread_arena().release(); }
 
 namespace {
 
-constexpr u32 DIGIT_ZERO = 0x7fffu; // "+2^15" cannot occur with the recoding below, so it encodes digit 0
-constexpr int GROUP = 4;            // buckets per k_reduce_groups thread
 
 struct CurveBn254 {
     typedef Bn254Fq Fq;
@@ -192,276 +191,6 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ w
     store_words<2 * L>(out + i * 2 * L, o);
 }
 
-// scalar (Montgomery wire form) -> W signed digits.  code = (neg << 15) | (|d| - 1), DIGIT_ZERO for d = 0.
-// Replaces init_handle_scalars_kernel + the slice extraction of calc_lens/fill_arrs (msm_cuda.cuh:148-205,232-282).
-// Window layout: BITS+1 scalar bits (one spare for the signed-digit carry) cut into W windows whose widths differ by
-// at most one, so that the top window is as wide as the others (a narrow top window would put all n points into a
-// handful of buckets).  width[k] <= 16.
-struct WindowPlan {
-    unsigned W;
-    unsigned char width[64];
-    unsigned short lo[64];
-};
-
-template <class Fr>
-__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, uint16_t *__restrict__ dig, u64 n, WindowPlan plan)
-{
-    constexpr int L = Fr::L;
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[L], s[L + 1];
-    load_words<L>(w, scalars + i * L);
-    fe_wire_to_canonical<Fr>(s, w);
-    s[L] = 0;
-    u32 carry = 0;
-    for (unsigned k = 0; k < plan.W; k++) {
-        const unsigned c = plan.width[k];
-        const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-        unsigned lo = plan.lo[k], m = lo >> 5, sh = lo & 31;
-        u32 raw = 0;
-        if (m < (unsigned)L) {
-            u64 v = s[m] | ((u64)s[m + 1] << 32);
-            raw = (u32)(v >> sh) & mask;
-        }
-        raw += carry;
-        u32 code;
-        if (raw >= half) { // negative digit raw - 2^c (or zero when raw == 2^c)
-            u32 mag = full - raw;
-            carry = 1;
-            code = mag ? (0x8000u | (mag - 1)) : DIGIT_ZERO;
-        } else {
-            carry = 0;
-            code = raw ? (raw - 1) : DIGIT_ZERO;
-        }
-        dig[(u64)k * n + i] = (uint16_t)code;
-    }
-}
-
-// ---- (window, bucket) -> point-id lists: two-level partition sort staged in LDS --------------------------------
-// Replaces the reference's three global-atomic passes (calc_lens / allo_arrs / fill_arrs, msm_cuda.cuh:159-282).
-// Bucket ids are split into `hi` (partition) and `lo` bits.  Level 1 moves every (id, sign, lo) word into its
-// partition with per-tile LDS histograms and LDS cursors; level 2 gives each partition to one workgroup, which
-// counts and ranks its `lo` values in LDS and writes the final order.  A partition's output range equals its
-// input range, so no global prefix over the 2^(c-1) buckets is needed.  No global atomics anywhere.
-constexpr unsigned SORT_TILE = 8192; // digits per workgroup in level 1
-constexpr unsigned MAX_PARTS = 1024;
-
-struct SortGeom {
-    unsigned log_n, lo_bits, H, tiles;
-};
-
-__global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ dig, u32 *__restrict__ tile_hist, SortGeom g)
-{
-    __shared__ u32 h[MAX_PARTS];
-    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    for (unsigned i = tid; i < g.H; i += 256) h[i] = 0;
-    __syncthreads();
-    const u64 n = (u64)1 << g.log_n;
-    const uint16_t *dw = dig + ((u64)w << g.log_n);
-    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
-    for (u64 i = begin + tid; i < end; i += 256) {
-        u32 code = dw[i];
-        if (code != DIGIT_ZERO) atomicAdd(&h[(code & 0x7fffu) >> g.lo_bits], 1u);
-    }
-    __syncthreads();
-    u32 *out = tile_hist + ((u64)w * g.tiles + tile) * g.H;
-    for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
-}
-
-// tile_hist -> exclusive prefix over tiles (in place), one WAVE per (window, partition) column: 64 tiles per step with a
-// shuffle scan instead of one dependent load per tile; column totals go to `totals`
-__global__ void __launch_bounds__(1024) k_part_scan_cols(u32 *__restrict__ tile_hist, u32 *__restrict__ totals, SortGeom g)
-{
-    const unsigned w = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
-    if (h >= g.H) return; // whole wave exits together
-    u32 *col = tile_hist + (u64)w * g.tiles * g.H + h;
-    u32 run = 0;
-    for (unsigned t0 = 0; t0 < g.tiles; t0 += 64) {
-        const unsigned tile = t0 + lane;
-        u32 v = tile < g.tiles ? col[(u64)tile * g.H] : 0;
-        u32 inc = v;
-        for (unsigned d = 1; d < 64; d <<= 1) {
-            u32 up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
-        }
-        if (tile < g.tiles) col[(u64)tile * g.H] = run + inc - v;
-        run += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) totals[(u64)w * g.H + h] = run;
-}
-
-// one block per window: exclusive scan of the H column totals -> part_off[w][0..H]
-__global__ void __launch_bounds__(1024) k_part_offsets(const u32 *__restrict__ totals, u32 *__restrict__ part_off, SortGeom g)
-{
-    __shared__ u32 tot[MAX_PARTS];
-    const unsigned w = blockIdx.x, t = threadIdx.x;
-    const u32 mine = t < g.H ? totals[(u64)w * g.H + t] : 0;
-    tot[t] = mine;
-    __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) {
-        u32 v = (t >= d) ? tot[t - d] : 0;
-        __syncthreads();
-        tot[t] += v;
-        __syncthreads();
-    }
-    if (t < g.H) part_off[(u64)w * (g.H + 1) + t] = tot[t] - mine;
-    if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
-}
-
-constexpr unsigned SORT_THREADS = 1024; // 16 waves per workgroup: these kernels wait on LDS atomics and HBM, they need the occupancy
-
-// block-wide exclusive scan of `count` (<= 1024) LDS words in place by SORT_THREADS threads
-__device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32 *scratch /* SORT_THREADS words */)
-{
-    const unsigned tid = threadIdx.x;
-    const unsigned per = (count + SORT_THREADS - 1) / SORT_THREADS;
-    u32 local = 0;
-    for (unsigned j = 0; j < per; j++) {
-        unsigned i = tid * per + j;
-        if (i < count) local += a[i];
-    }
-    scratch[tid] = local;
-    __syncthreads();
-    for (unsigned d = 1; d < SORT_THREADS; d <<= 1) {
-        u32 v = (tid >= d) ? scratch[tid - d] : 0;
-        __syncthreads();
-        scratch[tid] += v;
-        __syncthreads();
-    }
-    u32 run = scratch[tid] - local;
-    for (unsigned j = 0; j < per; j++) {
-        unsigned i = tid * per + j;
-        if (i < count) {
-            u32 v = a[i];
-            a[i] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-}
-
-// word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n].
-// The tile is first grouped by partition in LDS (local counting sort), then written out linearly, so that a wave
-// stores runs of consecutive addresses instead of 64 unrelated 4-byte words.
-__global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const uint16_t *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
-                                                      u32 *__restrict__ p1, SortGeom g)
-{
-    __shared__ u32 lstart[MAX_PARTS]; // local start of each partition's run in the staging buffer
-    __shared__ u32 lcur[MAX_PARTS];   // local cursor
-    __shared__ u32 gbase[MAX_PARTS];  // global position of this tile's first element of the partition
-    __shared__ u32 words[SORT_TILE];
-    __shared__ uint16_t parts_of[SORT_TILE];
-    __shared__ u32 scratch[SORT_THREADS];
-    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
-    const u32 *po = part_off + (u64)w * (g.H + 1);
-    for (unsigned i = tid; i < g.H; i += SORT_THREADS) {
-        lstart[i] = 0;
-        lcur[i] = 0;
-        gbase[i] = po[i] + base[i];
-    }
-    __syncthreads();
-    const u64 n = (u64)1 << g.log_n;
-    const uint16_t *dw = dig + ((u64)w << g.log_n);
-    u32 *pw = p1 + ((u64)w << g.log_n);
-    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
-    const u32 lo_mask = (1u << g.lo_bits) - 1;
-    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
-        u32 code = dw[i];
-        if (code != DIGIT_ZERO) atomicAdd(&lstart[(code & 0x7fffu) >> g.lo_bits], 1u);
-    }
-    __syncthreads();
-    block_exclusive_scan(lstart, g.H, scratch);
-    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
-        u32 code = dw[i];
-        if (code == DIGIT_ZERO) continue;
-        u32 b = code & 0x7fffu, h = b >> g.lo_bits;
-        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
-        words[slot] = ((b & lo_mask) << (g.log_n + 1)) | ((code >> 15) << g.log_n) | (u32)i;
-        parts_of[slot] = (uint16_t)h;
-    }
-    __syncthreads();
-    const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
-    for (u32 j = tid; j < total; j += SORT_THREADS) {
-        u32 h = parts_of[j];
-        pw[gbase[h] + (j - lstart[h])] = words[j];
-    }
-}
-
-// one workgroup per (partition, window): count the lo values, publish the bucket offsets, then rank the ids chunk by
-// chunk in LDS and write each chunk out as runs
-constexpr unsigned BS_CHUNK = 8192;
-
-__global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
-                                                     u32 *__restrict__ sorted, SortGeom g, unsigned NB)
-{
-    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
-    __shared__ u32 words[BS_CHUNK];
-    __shared__ unsigned char lo_of[BS_CHUNK];
-    const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
-    const unsigned L = 1u << g.lo_bits;
-    const u32 ps = part_off[(u64)w * (g.H + 1) + h], pe = part_off[(u64)w * (g.H + 1) + h + 1];
-    const u32 *pw = p1 + ((u64)w << g.log_n);
-    u32 *sw = sorted + ((u64)w << g.log_n);
-    const unsigned shift = g.log_n + 1;
-    if (tid < 128) cnt[tid] = 0;
-    __syncthreads();
-    for (u32 j = ps + tid; j < pe; j += SORT_THREADS) atomicAdd(&cnt[pw[j] >> shift], 1u);
-    __syncthreads();
-    u32 mine = tid < 128 ? cnt[tid] : 0;
-    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
-        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
-        __syncthreads();
-        if (tid < 128) cnt[tid] += v;
-        __syncthreads();
-    }
-    if (tid < L) {
-        u32 start = ps + cnt[tid] - mine;
-        cur[tid] = start;
-        off[(u64)w * (NB + 1) + ((u64)h << g.lo_bits) + tid] = start;
-    }
-    if (h == g.H - 1 && tid == 0) off[(u64)w * (NB + 1) + NB] = pe;
-    __syncthreads();
-    const u32 id_mask = (1u << g.log_n) - 1;
-    for (u32 cbeg = ps; cbeg < pe; cbeg += BS_CHUNK) { // pe, ps are uniform over the block: barriers are safe
-        const u32 cend = min(cbeg + BS_CHUNK, pe);
-        if (tid < 128) {
-            lstart[tid] = 0;
-            lcur[tid] = 0;
-        }
-        __syncthreads();
-        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) atomicAdd(&lstart[pw[j] >> shift], 1u);
-        __syncthreads();
-        u32 c0 = tid < 128 ? lstart[tid] : 0;
-        for (unsigned d = 1; d < 128; d <<= 1) {
-            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
-            __syncthreads();
-            if (tid < 128) lstart[tid] += v;
-            __syncthreads();
-        }
-        if (tid < 128) {
-            lstart[tid] -= c0; // exclusive
-            cnt[tid] = c0;
-        }
-        __syncthreads();
-        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) {
-            u32 v = pw[j];
-            u32 l = v >> shift;
-            u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
-            words[slot] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
-            lo_of[slot] = (unsigned char)l;
-        }
-        __syncthreads();
-        for (u32 j = tid; j < cend - cbeg; j += SORT_THREADS) {
-            u32 l = lo_of[j];
-            sw[cur[l] + (j - lstart[l])] = words[j];
-        }
-        __syncthreads();
-        if (tid < 128) cur[tid] += cnt[tid];
-        __syncthreads();
-    }
-}
-
 // first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
 __device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
 {
@@ -509,7 +238,7 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 // Replaces aggerate_buckets_groups_kernel's per-bucket list walk (msm_cuda.cuh:373-409).
 template <class F>
 __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
-                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, unsigned log_n, unsigned NB, unsigned K,
+                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
                                                     unsigned chunks)
 {
     constexpr int PW = 4 * F::N;
@@ -521,7 +250,7 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     const u32 start = t * K;
     if (start >= nw) return;
     const u32 end = min(start + K, nw);
-    const u32 *sw = sorted + ((u64)w << log_n);
+    const u32 *sw = sorted + (u64)w * stride;
     u32 *pw = parts + ((u64)w * chunks + t) * 2 * PW;
     u32 *bw = bucket_acc + (u64)w * NB * PW;
 
@@ -668,11 +397,11 @@ __device__ __forceinline__ void xyzz_mul_small(Xyzz<F> &r, const Xyzz<F> &p, u32
     r = acc;
 }
 
-// thread (w, g): buckets b = g*GROUP .. g*GROUP+GROUP-1, weights b+1.
-//   running sums from the top give S = sum B_j and T = sum (j+1) B_j (j local); the partial is T + (g*GROUP) * S.
+// thread (w, g): buckets b = g*group .. g*group+group-1, weights b+1.
+//   running sums from the top give S = sum B_j and T = sum (j+1) B_j (j local); the partial is T + (g*group) * S.
 // Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420.
 template <class F>
-__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ out, unsigned NB, unsigned groups)
+__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ out, unsigned NB, unsigned groups, unsigned group)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
@@ -682,15 +411,16 @@ __global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ b
     Xyzz<F> run, sum, q;
     xyzz_set_identity(run);
     xyzz_set_identity(sum);
-    for (int j = GROUP - 1; j >= 0; j--) {
-        u32 b = g * GROUP + j;
+#pragma unroll 1
+    for (int j = (int)group - 1; j >= 0; j--) {
+        u32 b = g * group + j;
         if (b < NB) {
             load_xyzz<F>(q, bw + (u64)b * PW);
             xyzz_add(run, q);
         }
         xyzz_add(sum, run);
     }
-    xyzz_mul_small(q, run, g * GROUP);
+    xyzz_mul_small(q, run, g * group);
     xyzz_add(sum, q);
     store_xyzz<F>(out + ((u64)w * groups + g) * PW, sum);
 }
@@ -722,32 +452,75 @@ __global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in,
     if (t == 0) store_xyzz<F>(out + ((u64)w * gridDim.x + blk) * PW, acc);
 }
 
+// Precomputed window tables for cached bases (the reference left the idea as a stub,
+// msm_host.cuh:248-265): row i of table k+1 is 2^width[k] times row i of table k, back in affine form, so that
+// digit d_k of scalar i is served by the single addition  d_k * T_k[i]  into a bucket space shared by all windows.
+template <class F>
+__global__ void __launch_bounds__(128) k_table_step(const u32 *__restrict__ prev, u32 *__restrict__ next, u64 n, unsigned steps)
+{
+    constexpr int L = F::L;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PackedBase<F> b;
+    load_words<2 * L>(b.w, prev + i * 2 * L);
+    Fe<F> x, y;
+    bool inf;
+    unpack_base<F>(x, y, inf, b, 0u);
+    u32 o[2 * L];
+    if (inf) {
+#pragma unroll
+        for (int k = 0; k < 2 * L; k++) o[k] = 0;
+    } else {
+        Xyzz<F> p, d;
+        xyzz_dbl_affine(p, x, y);
+#pragma unroll 1
+        for (unsigned s = 1; s < steps; s++) { // the group has odd order: a doubling never reaches the identity
+            xyzz_dbl(d, p);
+            p = d;
+        }
+        xyzz_to_affine_internal(x, y, p);
+        fe_reduce_once(x);
+        fe_reduce_once(y);
+        fe_pack(o, x);
+        fe_pack(o + L, y);
+    }
+    store_words<2 * L>(next + i * 2 * L, o);
+}
+
 // ------------------------------------------------------------------------------- host side
 
 thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 
 // Cached bases (README "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): a caller that keeps a base
 // set on the device for many MSMs may register it; the radix conversion k_convert_bases would repeat on every call is
-// then done once and kept next to it.  The caller promises not to modify a registered buffer until it is unregistered.
+// then done once and kept next to it -- optionally together with the window tables above.  The caller promises not to
+// modify a registered buffer until it is unregistered.
 struct RegisteredBases {
     const void *wire; // the caller's device pointer (the key)
-    void *converted;
+    void *converted;  // n rows (plain) or plan.W tables of n rows (tabled)
     unsigned log_n, curve;
     int device;
+    bool tabled;
+    panda::WindowPlan plan;
+    size_t bytes;
 };
 std::mutex g_registry_mutex;
 std::vector<RegisteredBases> g_registry;
 
-const void *lookup_registered(const void *wire, unsigned log_n, unsigned curve)
+bool lookup_registered(RegisteredBases &out, const void *wire, unsigned log_n, unsigned curve)
 {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     for (const auto &r : g_registry)
-        if (r.wire == wire && r.log_n == log_n && r.curve == curve && r.device == dev) return r.converted;
-    return nullptr;
+        if (r.wire == wire && r.log_n == log_n && r.curve == curve && r.device == dev) {
+            out = r;
+            return true;
+        }
+    return false;
 }
 unsigned g_window_override = 0;
+unsigned g_reduce_group = 0;
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
@@ -760,22 +533,26 @@ unsigned pick_window_bits(unsigned log_n)
     return (unsigned)std::min(std::max(c, 4), 16);
 }
 
-WindowPlan make_plan(unsigned total_bits, unsigned c)
+// window width for precomputed tables: all windows share one bucket space, so wide windows are cheap --
+// minimise (additions) n * W(c) + (bucket reduction) ~8 * 2^(c-1) over the widths the sort supports
+unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 {
-    WindowPlan p{};
-    p.W = (total_bits + c - 1) / c;
-    const unsigned base = total_bits / p.W, rem = total_bits % p.W;
-    unsigned lo = 0;
-    for (unsigned k = 0; k < p.W; k++) {
-        p.width[k] = (unsigned char)(base + (k < rem ? 1 : 0));
-        p.lo[k] = (unsigned short)lo;
-        lo += p.width[k];
+    unsigned best = 0;
+    double best_cost = 0;
+    for (unsigned c = 10; c <= 23; c++) {
+        const panda::WindowPlan plan = panda::make_safe_window_plan(fr, c);
+        if (plan.width[0] != c || !panda::msm_sort_tabled_supported(log_n, plan)) continue;
+        const double cost = (double)plan.W * (double)((u64)1 << log_n) + 8.0 * (double)(1u << (c - 1));
+        if (!best || cost < best_cost) {
+            best = c;
+            best_cost = cost;
+        }
     }
-    return p;
+    return best;
 }
 
 template <class F>
-void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, const WindowPlan &plan)
+void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, const panda::WindowPlan &plan)
 {
     Xyzz<F> acc, d;
     xyzz_set_identity(acc);
@@ -789,68 +566,57 @@ void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, const Win
     result = acc;
 }
 
+unsigned floor_log2(u64 v)
+{
+    unsigned l = 0;
+    while (v >> (l + 1)) l++;
+    return l;
+}
+
 template <class C>
 hipError_t msm_execute(const panda_msm_configuration &cfg)
 {
     typedef typename C::Fq Fq;
-    typedef typename C::Fr Fr;
     constexpr int PW = 4 * Fq::N;
-    constexpr int LQ = Fq::L, LR = Fr::L;
+    constexpr int LQ = Fq::L;
+    constexpr unsigned curve = Fq::N == 9 ? 0u : 1u; // also selects the scalar field in msm_sort
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     const unsigned log_n = cfg.log_scalars_count;
     if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
-    // BITS + 1: one spare bit for the signed-digit carry.  The top window must never carry out: its largest raw value
-    // (top bits of r - 1, plus a carry in) has to stay below half its range; widen the plan by a bit until it does.
-    WindowPlan plan{};
-    for (unsigned total = Fr::BITS + 1;; total++) {
-        plan = make_plan(total, pick_window_bits(log_n));
-        const unsigned lo = plan.lo[plan.W - 1], m = lo >> 5, sh = lo & 31;
-        u64 top = m < (unsigned)LR ? ((u64)Fr::PW[m] >> sh) : 0;
-        if (m + 1 < (unsigned)LR) top |= (u64)Fr::PW[m + 1] << (32 - sh);
-        if (m + 2 < (unsigned)LR && sh) top |= (u64)Fr::PW[m + 2] << (64 - sh);
-        if (top + 1 < ((u64)1 << (plan.width[plan.W - 1] - 1)) || total > Fr::BITS + 8) break;
-    }
+
+    RegisteredBases reg{};
+    const bool registered = lookup_registered(reg, cfg.bases, log_n, curve);
+    const bool tabled = registered && reg.tabled;
+    const panda::WindowPlan plan = tabled ? reg.plan : panda::make_safe_window_plan(curve, pick_window_bits(log_n));
     const unsigned W = plan.W;
     const unsigned c = plan.width[0]; // widest window
     const unsigned NB = 1u << (c - 1);
-    const unsigned K = log_n >= 24 ? 128 : (log_n >= 22 ? 64 : (log_n >= 16 ? 32 : 16)); // sorted entries per accumulate thread
-    const unsigned chunks = (unsigned)((n + K - 1) / K);
-    const unsigned groups = (NB + GROUP - 1) / GROUP;
-    const unsigned lvl1 = (groups + 255) / 256 > 64 ? 64 : (groups + 255) / 256; // blocks in the first tree level
+    const unsigned lists = tabled ? 1u : W;         // independent bucket spaces
+    const u64 stride = tabled ? (u64)W << log_n : n; // entries per list (upper bound)
+    const unsigned lg = floor_log2(stride);
+    const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16)); // sorted entries per accumulate thread
+    const unsigned chunks = (unsigned)((stride + K - 1) / K);
+    const unsigned group = g_reduce_group ? g_reduce_group : (NB >= (1u << 18) ? 16u : 4u); // buckets per k_reduce_groups thread
+    const unsigned groups = (NB + group - 1) / group;
+    const unsigned lvl1_cap = lists == 1 ? 512u : 64u;
+    const unsigned lvl1 = std::min((groups + 255) / 256, lvl1_cap); // blocks in the first tree level
     const unsigned per1 = (groups + lvl1 - 1) / lvl1;
 
     // ---- scratch
-    const size_t sz_bases = panda::align256(n * 2 * LQ * 4);
-    const size_t sz_dig = panda::align256(n * W * 2);
-    SortGeom geom;
-    geom.log_n = log_n;
-    geom.lo_bits = std::min(std::min(7u, c - 1), 31u - log_n);
-    geom.H = 1u << (c - 1 - geom.lo_bits);
-    geom.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
-    if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
-    const size_t sz_thist = panda::align256((size_t)W * geom.tiles * geom.H * 4);
-    const size_t sz_poff = panda::align256((size_t)W * (geom.H + 1) * 4);
-    const size_t sz_off = panda::align256((size_t)W * (NB + 1) * 4);
-    const size_t sz_sorted = panda::align256(n * W * 4);
-    const size_t sz_bacc = panda::align256((size_t)W * NB * PW * 4);
-    const size_t sz_parts = panda::align256((size_t)W * chunks * 2 * PW * 4);
-    const size_t sz_gsum = panda::align256((size_t)W * groups * PW * 4);
-    const size_t sz_l1 = panda::align256((size_t)W * lvl1 * PW * 4);
-    const size_t sz_win = panda::align256((size_t)W * PW * 4);
+    const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
+    const size_t sz_sort = tabled ? panda::msm_sort_tabled_bytes(log_n, plan) : panda::msm_sort_plain_bytes(log_n, plan);
+    const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
+    const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
+    const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
+    const size_t sz_l1 = panda::align256((size_t)lists * lvl1 * PW * 4);
+    const size_t sz_win = panda::align256((size_t)lists * PW * 4);
     const unsigned long_cap = chunks / LONG_SPAN + 2;
-    const size_t sz_lcount = panda::align256((size_t)W * 4);
-    const size_t sz_llist = panda::align256((size_t)W * long_cap * 3 * 4);
+    const size_t sz_lcount = panda::align256((size_t)lists * 4);
+    const size_t sz_llist = panda::align256((size_t)lists * long_cap * 3 * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_dig + sz_thist + 2 * sz_poff + sz_off + 2 * sz_sorted + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 4096));
-    u32 *d_bases = (u32 *)arena.take(sz_bases);
-    uint16_t *d_dig = (uint16_t *)arena.take(sz_dig);
-    u32 *d_thist = (u32 *)arena.take(sz_thist);
-    u32 *d_poff = (u32 *)arena.take(sz_poff);
-    u32 *d_ptot = (u32 *)arena.take(sz_poff);
-    u32 *d_p1 = (u32 *)arena.take(sz_sorted);
-    u32 *d_off = (u32 *)arena.take(sz_off);
-    u32 *d_sorted = (u32 *)arena.take(sz_sorted);
+    PANDA_TRY(arena.reserve(sz_bases + sz_sort + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 8192));
+    const u32 *d_bases = registered ? (const u32 *)reg.converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
     u32 *d_parts = (u32 *)arena.take(sz_parts);
     u32 *d_gsum = (u32 *)arena.take(sz_gsum);
@@ -858,7 +624,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     u32 *d_win = (u32 *)arena.take(sz_win);
     u32 *d_lcount = (u32 *)arena.take(sz_lcount);
     u32 *d_llist = (u32 *)arena.take(sz_llist);
-    if (!d_win || !d_llist) return hipErrorOutOfMemory;
+    if (!d_bases || !d_bacc || !d_parts || !d_gsum || !d_l1 || !d_win || !d_lcount || !d_llist) return hipErrorOutOfMemory;
 
     struct PhaseEvents { // destroyed on every exit path
         hipEvent_t ev[8] = {};
@@ -873,41 +639,37 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
 
     PANDA_TRY(mark(0));
-    const unsigned blocks_n = (unsigned)((n + 255) / 256);
-    const u32 *registered = (const u32 *)lookup_registered(cfg.bases, log_n, Fq::N == 9 ? 0u : 1u);
-    if (registered)
-        d_bases = const_cast<u32 *>(registered); // converted once at registration
+    if (!registered)
+        hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
+    panda::SortResult sorted{};
+    const panda::SortEvents sort_events{ev[1], ev[2]};
+    if (tabled)
+        PANDA_TRY(panda::msm_sort_tabled(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
     else
-        hipLaunchKernelGGL(k_convert_bases<Fq>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.bases, d_bases, n);
-    hipLaunchKernelGGL(k_digits<Fr>, dim3(blocks_n), dim3(256), 0, stream, (const u32 *)cfg.scalars, d_dig, n, plan);
-    PANDA_TRY(mark(1));
-    hipLaunchKernelGGL(k_part_hist, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
-    hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_ptot, geom);
-    hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, geom);
-    hipLaunchKernelGGL(k_part_scatter, dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
-    PANDA_TRY(mark(2));
-    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
+        PANDA_TRY(panda::msm_sort_plain(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
+    if (sorted.lists != lists || sorted.NB != NB || sorted.stride != stride) return hipErrorInvalidValue;
     PANDA_TRY(mark(3));
     PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
-    hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, W), dim3(128), 0, stream, d_bases, d_sorted, d_off, d_bacc, d_parts, log_n, NB, K,
-                       chunks);
+    hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, lists), dim3(128), 0, stream, d_bases, sorted.sorted, sorted.off, d_bacc, d_parts, stride,
+                       NB, K, chunks);
     PANDA_TRY(mark(4));
     PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
-    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, W), dim3(128), 0, stream, d_off, d_parts, d_bacc, NB, K, chunks, d_lcount, d_llist, long_cap);
-    hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, W), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
+    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, d_bacc, NB, K, chunks, d_lcount, d_llist,
+                       long_cap);
+    hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
     PANDA_TRY(mark(5));
-    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, W), dim3(128), 0, stream, d_bacc, d_gsum, NB, groups);
-    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(lvl1, W), dim3(256), 0, stream, d_gsum, d_l1, groups, per1);
-    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(1, W), dim3(256), 0, stream, d_l1, d_win, lvl1, lvl1);
+    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, NB, groups, group);
+    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(lvl1, lists), dim3(256), 0, stream, d_gsum, d_l1, groups, per1);
+    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(1, lists), dim3(256), 0, stream, d_l1, d_win, lvl1, lvl1);
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
 
-    std::vector<u32> h_win((size_t)W * PW);
-    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, (size_t)W * PW * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<u32> h_win((size_t)lists * PW);
+    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, (size_t)lists * PW * 4, hipMemcpyDeviceToHost, stream));
     PANDA_TRY(hipStreamSynchronize(stream));
 
-    std::vector<Xyzz<Fq>> windows(W);
-    for (unsigned w = 0; w < W; w++) {
+    std::vector<Xyzz<Fq>> windows(lists);
+    for (unsigned w = 0; w < lists; w++) {
         const u32 *src = h_win.data() + (size_t)w * PW;
         for (int i = 0; i < Fq::N; i++) {
             windows[w].X.l[i] = src[i];
@@ -917,7 +679,10 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
         }
     }
     Xyzz<Fq> result;
-    host_horner(result, windows, plan);
+    if (tabled)
+        result = windows[0]; // the tables already carry the 2^lo[k] factors
+    else
+        host_horner(result, windows, plan);
     u32 out[3 * LQ];
     if (cfg.msm_result_coordinate_type == PROJECTIVE)
         xyzz_to_homogeneous_wire(out, result);
@@ -937,7 +702,54 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     g_phase_ms[6] = ms;
     (void)hipEventElapsedTime(&ms, ev[0], ev[6]);
     g_phase_ms[7] = ms;
-    (void)LR;
+    return hipSuccess;
+}
+
+template <class Fq>
+hipError_t build_registration(RegisteredBases &r, hipStream_t s)
+{
+    const u64 n = (u64)1 << r.log_n;
+    const size_t row = 2 * Fq::L * 4;
+    const unsigned tables = r.tabled ? r.plan.W : 1u;
+    r.bytes = (size_t)tables * n * row;
+    PANDA_TRY(hipMalloc(&r.converted, r.bytes));
+    u32 *t0 = (u32 *)r.converted;
+    hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32 *)r.wire, t0, n);
+    for (unsigned k = 1; k < tables; k++)
+        hipLaunchKernelGGL(k_table_step<Fq>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, t0 + (size_t)(k - 1) * n * 2 * Fq::L,
+                           t0 + (size_t)k * n * 2 * Fq::L, n, (unsigned)r.plan.width[k - 1]);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipFree(r.converted);
+        r.converted = nullptr;
+    }
+    return e;
+}
+
+hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
+{
+    if (curve > 1 || !d_bases || log_n > 26) return hipErrorInvalidValue;
+    RegisteredBases r{};
+    if (lookup_registered(r, d_bases, log_n, curve)) {
+        if (r.tabled == tabled && (!tabled || !window_bits || r.plan.width[0] == window_bits)) return hipSuccess;
+        return hipErrorInvalidValue; // registered differently: unregister first
+    }
+    r = RegisteredBases{};
+    r.wire = d_bases;
+    r.log_n = log_n;
+    r.curve = curve;
+    r.tabled = tabled;
+    PANDA_TRY(hipGetDevice(&r.device));
+    if (tabled) {
+        const unsigned c = window_bits ? window_bits : pick_tabled_window_bits(curve, log_n);
+        if (c < 4 || c > 24) return hipErrorInvalidValue;
+        r.plan = panda::make_safe_window_plan(curve, c);
+        if (!panda::msm_sort_tabled_supported(log_n, r.plan)) return hipErrorInvalidValue;
+    }
+    PANDA_TRY(curve == 0 ? build_registration<Bn254Fq>(r, s) : build_registration<Bls377Fq>(r, s));
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry.push_back(r);
     return hipSuccess;
 }
 
@@ -954,29 +766,25 @@ panda_error panda_msm_tear_down(void) { return static_cast<panda_error>(panda::r
 
 panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream)
 {
-    if (curve > 1 || !d_bases || log_n > 26) return panda_error_invalid_value;
-    if (lookup_registered(d_bases, log_n, curve)) return panda_success;
-    const u64 n = (u64)1 << log_n;
-    const size_t bytes = n * (curve == 0 ? 64 : 96);
-    RegisteredBases r{d_bases, nullptr, log_n, curve, -1};
-    hipError_t e = hipGetDevice(&r.device);
-    if (e == hipSuccess) e = hipMalloc(&r.converted, bytes);
-    if (e != hipSuccess) return static_cast<panda_error>(e);
-    hipStream_t s = static_cast<hipStream_t>(stream.handle);
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (curve == 0)
-        hipLaunchKernelGGL(k_convert_bases<Bn254Fq>, dim3(blocks), dim3(256), 0, s, (const u32 *)d_bases, (u32 *)r.converted, n);
-    else
-        hipLaunchKernelGGL(k_convert_bases<Bls377Fq>, dim3(blocks), dim3(256), 0, s, (const u32 *)d_bases, (u32 *)r.converted, n);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        (void)hipFree(r.converted);
-        return static_cast<panda_error>(e);
-    }
+    return static_cast<panda_error>(register_bases(curve, d_bases, log_n, false, 0, static_cast<hipStream_t>(stream.handle)));
+}
+
+panda_error panda_msm_precompute_bases(unsigned curve, const void *d_bases, unsigned log_n, unsigned window_bits, panda_stream stream)
+{
+    return static_cast<panda_error>(register_bases(curve, d_bases, log_n, true, window_bits, static_cast<hipStream_t>(stream.handle)));
+}
+
+panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, unsigned *window_bits, size_t *bytes)
+{
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    g_registry.push_back(r);
-    return panda_success;
+    for (const auto &r : g_registry)
+        if (r.wire == d_bases) {
+            if (tables) *tables = r.tabled ? r.plan.W : 1u;
+            if (window_bits) *window_bits = r.tabled ? r.plan.width[0] : 0u;
+            if (bytes) *bytes = r.bytes;
+            return panda_success;
+        }
+    return panda_error_invalid_value;
 }
 
 panda_error panda_msm_unregister_bases(const void *d_bases)
@@ -1010,6 +818,13 @@ panda_error panda_msm_set_window_bits(unsigned window_bits)
 {
     if (window_bits > 16) return panda_error_invalid_value;
     g_window_override = window_bits;
+    return panda_success;
+}
+
+panda_error panda_msm_set_reduce_group(unsigned group)
+{
+    if (group > 64) return panda_error_invalid_value;
+    g_reduce_group = group;
     return panda_success;
 }
 

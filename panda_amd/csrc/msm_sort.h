@@ -1,0 +1,45 @@
+// msm_sort.h -- scalars -> signed window digits -> per-bucket point lists (the front half of the MSM pipeline).
+// Implemented in msm_sort.hip; consumed by msm.hip.  Replaces the reference's calc_lens / allo_arrs / fill_arrs
+// global-atomic passes (src/cuda/core/unit/msm/msm_cuda.cuh:159-282).
+#pragma once
+#include "panda_internal.h"
+
+namespace panda {
+
+// BITS+1 scalar bits (one spare for the signed-digit carry) cut into W windows whose widths differ by at most one.
+struct WindowPlan {
+    unsigned W;
+    unsigned char width[64];
+    unsigned short lo[64];
+};
+
+WindowPlan make_window_plan(unsigned total_bits, unsigned c);
+// plan for scalar field `fr` (0 = BN254 Fr, 1 = BLS12-377 Fr) whose top window can never carry out
+WindowPlan make_safe_window_plan(unsigned fr, unsigned c);
+
+struct SortResult {
+    const uint32_t *off;    // [lists][NB + 1] start of each bucket's run, off[NB] = number of entries of the list
+    const uint32_t *sorted; // [lists][stride] entries: bit 31 = negate, low bits = index into the base array
+    unsigned lists;         // W (plain) or 1 (tabled)
+    unsigned NB;            // buckets per list
+    uint64_t stride;        // n (plain) or W*n (tabled)
+};
+
+// optional events recorded on `stream` between the phases (may be null)
+struct SortEvents {
+    hipEvent_t digits_done, partition_done;
+};
+
+// Plain mode: W independent lists (one per window), entries index the caller's n bases.
+size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan);
+hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
+                          SortResult *out);
+
+// Tabled mode: one list over all windows; entry index = k * n + i names row i of table k (= 2^lo[k] * base i), so
+// every window falls into the same 2^(c-1) buckets and the window sums need no Horner step.
+bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan);
+size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan);
+hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
+                           SortResult *out);
+
+} // namespace panda

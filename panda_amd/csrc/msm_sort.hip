@@ -1,0 +1,853 @@
+// msm_sort.hip -- scalars -> signed window digits -> per-bucket point lists, for gfx950.
+//
+// Replaces the reference's three global-atomic passes (calc_lens / allo_arrs / fill_arrs,
+// src/cuda/core/unit/msm/msm_cuda.cuh:159-282) and its in-place scalar conversion (:148-157).
+// Everything here is an MSD partition sort staged in LDS: per-tile LDS histograms and cursors, tiles grouped in LDS
+// and written out as runs, no global atomics anywhere (the first version's global-atomic histogram + scatter cost
+// 33 ms at 2^24).
+//
+//   plain mode   (bases as the caller gave them): per window, level 1 splits the bucket id's high bits into
+//                partitions, level 2 gives each partition to a workgroup that ranks the low bits.
+//   tabled mode  (precomputed 2^lo[k] * P tables): all windows share one bucket space of up to 2^22 buckets, so the
+//                key is three digits deep: level 1 (per window), level 2 (per level-1 partition, ragged tiles),
+//                level 3 (one workgroup per (hi, mid) cell merges the W per-window runs and ranks the low bits).
+#include <algorithm>
+
+#include "fe29.h"
+#include "msm_sort.h"
+
+using namespace panda29;
+
+namespace {
+
+constexpr unsigned SORT_TILE = 8192; // entries per workgroup tile
+constexpr unsigned MAX_PARTS = 1024;
+constexpr unsigned SORT_THREADS = 1024; // 16 waves per workgroup: these kernels wait on LDS atomics and HBM, they need the occupancy
+constexpr unsigned BS_CHUNK = 8192;
+
+template <class Code>
+struct CodeTraits;
+template <>
+struct CodeTraits<uint16_t> {
+    static constexpr u32 ZERO = 0x7fffu; // "+2^15" cannot occur with the recoding below, so it encodes digit 0
+    static constexpr u32 MAG = 0x7fffu;
+    static constexpr int SIGN = 15;
+};
+template <>
+struct CodeTraits<u32> {
+    static constexpr u32 ZERO = 0x7fffffffu;
+    static constexpr u32 MAG = 0x7fffffffu;
+    static constexpr int SIGN = 31;
+};
+
+template <int WORDS>
+__device__ __forceinline__ void load_words(u32 *dst, const u32 *src)
+{
+    static_assert(WORDS % 4 == 0, "vector loads");
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; i++) {
+        uint4 v = s4[i];
+        dst[4 * i] = v.x;
+        dst[4 * i + 1] = v.y;
+        dst[4 * i + 2] = v.z;
+        dst[4 * i + 3] = v.w;
+    }
+}
+
+// scalar (Montgomery wire form) -> W signed digits.  code = (neg << SIGN) | (|d| - 1), ZERO for d = 0.
+// Replaces init_handle_scalars_kernel + the slice extraction of calc_lens/fill_arrs (msm_cuda.cuh:148-205,232-282);
+// the scalars are only read.
+template <class Fr, class Code>
+__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, Code *__restrict__ dig, u64 n, panda::WindowPlan plan)
+{
+    typedef CodeTraits<Code> CT;
+    constexpr int L = Fr::L;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[L], s[L + 1];
+    load_words<L>(w, scalars + i * L);
+    fe_wire_to_canonical<Fr>(s, w);
+    s[L] = 0;
+    u32 carry = 0;
+    for (unsigned k = 0; k < plan.W; k++) {
+        const unsigned c = plan.width[k];
+        const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+        unsigned lo = plan.lo[k], m = lo >> 5, sh = lo & 31;
+        u32 raw = 0;
+        if (m < (unsigned)L) {
+            u64 v = s[m] | ((u64)s[m + 1] << 32);
+            raw = (u32)(v >> sh) & mask;
+        }
+        raw += carry;
+        u32 code;
+        if (raw >= half) { // negative digit raw - 2^c (or zero when raw == 2^c)
+            u32 mag = full - raw;
+            carry = 1;
+            code = mag ? ((1u << CT::SIGN) | (mag - 1)) : CT::ZERO;
+        } else {
+            carry = 0;
+            code = raw ? (raw - 1) : CT::ZERO;
+        }
+        dig[(u64)k * n + i] = (Code)code;
+    }
+}
+
+// ---- level 1 (both modes): per window, bucket id high bits -> partition ------------------------------------------
+// Bucket ids are split into `hi` (partition) and `lo` bits.  Level 1 moves every [lo][sign][point id] word into its
+// partition with per-tile LDS histograms and LDS cursors.  A partition's output range equals its input range, so no
+// global prefix over the buckets is needed.
+
+struct SortGeom {
+    unsigned log_n, lo_bits, H, tiles;
+};
+
+template <class Code>
+__global__ void __launch_bounds__(256) k_part_hist(const Code *__restrict__ dig, u32 *__restrict__ tile_hist, SortGeom g)
+{
+    typedef CodeTraits<Code> CT;
+    __shared__ u32 h[MAX_PARTS];
+    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    for (unsigned i = tid; i < g.H; i += 256) h[i] = 0;
+    __syncthreads();
+    const u64 n = (u64)1 << g.log_n;
+    const Code *dw = dig + ((u64)w << g.log_n);
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    for (u64 i = begin + tid; i < end; i += 256) {
+        u32 code = dw[i];
+        if (code != CT::ZERO) atomicAdd(&h[(code & CT::MAG) >> g.lo_bits], 1u);
+    }
+    __syncthreads();
+    u32 *out = tile_hist + ((u64)w * g.tiles + tile) * g.H;
+    for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
+}
+
+// tile_hist -> exclusive prefix over tiles (in place), one WAVE per (window, partition) column: 64 tiles per step with a
+// shuffle scan instead of one dependent load per tile; column totals go to `totals`
+__global__ void __launch_bounds__(1024) k_part_scan_cols(u32 *__restrict__ tile_hist, u32 *__restrict__ totals, SortGeom g)
+{
+    const unsigned w = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (h >= g.H) return; // whole wave exits together
+    u32 *col = tile_hist + (u64)w * g.tiles * g.H + h;
+    u32 run = 0;
+    for (unsigned t0 = 0; t0 < g.tiles; t0 += 64) {
+        const unsigned tile = t0 + lane;
+        u32 v = tile < g.tiles ? col[(u64)tile * g.H] : 0;
+        u32 inc = v;
+        for (unsigned d = 1; d < 64; d <<= 1) {
+            u32 up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (tile < g.tiles) col[(u64)tile * g.H] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) totals[(u64)w * g.H + h] = run;
+}
+
+// one block per window: exclusive scan of the H column totals -> part_off[w][0..H]
+__global__ void __launch_bounds__(1024) k_part_offsets(const u32 *__restrict__ totals, u32 *__restrict__ part_off, SortGeom g)
+{
+    __shared__ u32 tot[MAX_PARTS];
+    const unsigned w = blockIdx.x, t = threadIdx.x;
+    const u32 mine = t < g.H ? totals[(u64)w * g.H + t] : 0;
+    tot[t] = mine;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 v = (t >= d) ? tot[t - d] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    if (t < g.H) part_off[(u64)w * (g.H + 1) + t] = tot[t] - mine;
+    if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
+}
+
+// block-wide exclusive scan of `count` LDS words in place by SORT_THREADS threads
+__device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32 *scratch /* SORT_THREADS words */)
+{
+    const unsigned tid = threadIdx.x;
+    const unsigned per = (count + SORT_THREADS - 1) / SORT_THREADS;
+    u32 local = 0;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned i = tid * per + j;
+        if (i < count) local += a[i];
+    }
+    scratch[tid] = local;
+    __syncthreads();
+    for (unsigned d = 1; d < SORT_THREADS; d <<= 1) {
+        u32 v = (tid >= d) ? scratch[tid - d] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    u32 run = scratch[tid] - local;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned i = tid * per + j;
+        if (i < count) {
+            u32 v = a[i];
+            a[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+}
+
+// word written to the partition buffer: [lo : lo_bits][sign : 1][point id : log_n].
+// The tile is first grouped by partition in LDS (local counting sort), then written out linearly, so that a wave
+// stores runs of consecutive addresses instead of 64 unrelated words.
+template <class Code, class Word>
+__global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
+                                                      Word *__restrict__ p1, SortGeom g)
+{
+    typedef CodeTraits<Code> CT;
+    __shared__ u32 lstart[MAX_PARTS]; // local start of each partition's run in the staging buffer
+    __shared__ u32 lcur[MAX_PARTS];   // local cursor
+    __shared__ u32 gbase[MAX_PARTS];  // global position of this tile's first element of the partition
+    __shared__ Word words[SORT_TILE];
+    __shared__ uint16_t parts_of[SORT_TILE];
+    __shared__ u32 scratch[SORT_THREADS];
+    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
+    const u32 *po = part_off + (u64)w * (g.H + 1);
+    for (unsigned i = tid; i < g.H; i += SORT_THREADS) {
+        lstart[i] = 0;
+        lcur[i] = 0;
+        gbase[i] = po[i] + base[i];
+    }
+    __syncthreads();
+    const u64 n = (u64)1 << g.log_n;
+    const Code *dw = dig + ((u64)w << g.log_n);
+    Word *pw = p1 + ((u64)w << g.log_n);
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    const u32 lo_mask = (1u << g.lo_bits) - 1;
+    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
+        u32 code = dw[i];
+        if (code != CT::ZERO) atomicAdd(&lstart[(code & CT::MAG) >> g.lo_bits], 1u);
+    }
+    __syncthreads();
+    block_exclusive_scan(lstart, g.H, scratch);
+    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
+        u32 code = dw[i];
+        if (code == CT::ZERO) continue;
+        u32 b = code & CT::MAG, h = b >> g.lo_bits;
+        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
+        words[slot] = ((Word)(b & lo_mask) << (g.log_n + 1)) | (Word)(((code >> CT::SIGN) << g.log_n) | (u32)i);
+        parts_of[slot] = (uint16_t)h;
+    }
+    __syncthreads();
+    const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
+    for (u32 j = tid; j < total; j += SORT_THREADS) {
+        u32 h = parts_of[j];
+        pw[gbase[h] + (j - lstart[h])] = words[j];
+    }
+}
+
+// ---- plain mode, level 2: one workgroup per (partition, window) counts the lo values, publishes the bucket offsets,
+// then ranks the ids chunk by chunk in LDS and writes each chunk out as runs
+__global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
+                                                     u32 *__restrict__ sorted, SortGeom g, unsigned NB)
+{
+    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
+    __shared__ u32 words[BS_CHUNK];
+    __shared__ unsigned char lo_of[BS_CHUNK];
+    const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+    const unsigned L = 1u << g.lo_bits;
+    const u32 ps = part_off[(u64)w * (g.H + 1) + h], pe = part_off[(u64)w * (g.H + 1) + h + 1];
+    const u32 *pw = p1 + ((u64)w << g.log_n);
+    u32 *sw = sorted + ((u64)w << g.log_n);
+    const unsigned shift = g.log_n + 1;
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    for (u32 j = ps + tid; j < pe; j += SORT_THREADS) atomicAdd(&cnt[pw[j] >> shift], 1u);
+    __syncthreads();
+    u32 mine = tid < 128 ? cnt[tid] : 0;
+    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
+        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
+        __syncthreads();
+        if (tid < 128) cnt[tid] += v;
+        __syncthreads();
+    }
+    if (tid < L) {
+        u32 start = ps + cnt[tid] - mine;
+        cur[tid] = start;
+        off[(u64)w * (NB + 1) + ((u64)h << g.lo_bits) + tid] = start;
+    }
+    if (h == g.H - 1 && tid == 0) off[(u64)w * (NB + 1) + NB] = pe;
+    __syncthreads();
+    const u32 id_mask = (1u << g.log_n) - 1;
+    for (u32 cbeg = ps; cbeg < pe; cbeg += BS_CHUNK) { // pe, ps are uniform over the block: barriers are safe
+        const u32 cend = min(cbeg + BS_CHUNK, pe);
+        if (tid < 128) {
+            lstart[tid] = 0;
+            lcur[tid] = 0;
+        }
+        __syncthreads();
+        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) atomicAdd(&lstart[pw[j] >> shift], 1u);
+        __syncthreads();
+        u32 c0 = tid < 128 ? lstart[tid] : 0;
+        for (unsigned d = 1; d < 128; d <<= 1) {
+            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
+            __syncthreads();
+            if (tid < 128) lstart[tid] += v;
+            __syncthreads();
+        }
+        if (tid < 128) {
+            lstart[tid] -= c0; // exclusive
+            cnt[tid] = c0;
+        }
+        __syncthreads();
+        for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) {
+            u32 v = pw[j];
+            u32 l = v >> shift;
+            u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
+            words[slot] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
+            lo_of[slot] = (unsigned char)l;
+        }
+        __syncthreads();
+        for (u32 j = tid; j < cend - cbeg; j += SORT_THREADS) {
+            u32 l = lo_of[j];
+            sw[cur[l] + (j - lstart[l])] = words[j];
+        }
+        __syncthreads();
+        if (tid < 128) cur[tid] += cnt[tid];
+        __syncthreads();
+    }
+}
+
+// ---- tabled mode, level 2: ragged segments ---------------------------------------------------------------------------
+// Segment s = k * H1 + h1 is level-1 partition h1 of window k: positions [k*n + part_off[k][h1], k*n + part_off[k][h1+1])
+// of p1.  Its tiles are numbered seg_tile[s] .. seg_tile[s+1]-1; the launch covers an upper bound of tiles and a
+// workgroup finds its segment by binary search.
+
+struct TabledGeom {
+    unsigned log_n, W;
+    unsigned b1, b2, b3; // bucket id = [b1][b2][b3]
+    unsigned H1, H2, S;  // 2^b1, 2^b2, W * H1
+    unsigned max_tiles2; // launch bound for the level-2 tile kernels
+    unsigned Q;          // H1 * H2 cells
+};
+
+// one workgroup: seg_tile[0..S] = exclusive prefix of ceil(len_s / SORT_TILE)
+__global__ void __launch_bounds__(SORT_THREADS) k2_seg_tiles(const u32 *__restrict__ part_off, u32 *__restrict__ seg_tile, TabledGeom g)
+{
+    __shared__ u32 scratch[SORT_THREADS];
+    const unsigned tid = threadIdx.x;
+    const unsigned per = (g.S + SORT_THREADS - 1) / SORT_THREADS;
+    u32 local = 0;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned s = tid * per + j;
+        if (s < g.S) {
+            unsigned k = s / g.H1, h1 = s % g.H1;
+            const u32 *po = part_off + (u64)k * (g.H1 + 1);
+            local += (po[h1 + 1] - po[h1] + SORT_TILE - 1) / SORT_TILE;
+        }
+    }
+    scratch[tid] = local;
+    __syncthreads();
+    for (unsigned d = 1; d < SORT_THREADS; d <<= 1) {
+        u32 v = (tid >= d) ? scratch[tid - d] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    u32 run = scratch[tid] - local;
+    for (unsigned j = 0; j < per; j++) {
+        unsigned s = tid * per + j;
+        if (s < g.S) {
+            unsigned k = s / g.H1, h1 = s % g.H1;
+            const u32 *po = part_off + (u64)k * (g.H1 + 1);
+            seg_tile[s] = run;
+            run += (po[h1 + 1] - po[h1] + SORT_TILE - 1) / SORT_TILE;
+        }
+    }
+    if (tid == SORT_THREADS - 1) seg_tile[g.S] = scratch[SORT_THREADS - 1];
+}
+
+struct TileRange {
+    unsigned s;     // segment
+    u64 begin, end; // positions in p1 / p2
+    u64 seg_begin;
+};
+
+// tile -> (segment, range); false if the tile index is beyond the last tile (uniform over the workgroup)
+__device__ __forceinline__ bool locate_tile(TileRange &r, unsigned tile, const u32 *seg_tile, const u32 *part_off, const TabledGeom &g)
+{
+    if (tile >= seg_tile[g.S]) return false;
+    unsigned lo = 0, hi = g.S; // invariant: seg_tile[lo] <= tile < seg_tile[hi]
+    while (hi - lo > 1) {
+        unsigned mid = (lo + hi) >> 1;
+        if (seg_tile[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    r.s = lo;
+    const unsigned k = lo / g.H1, h1 = lo % g.H1;
+    const u32 *po = part_off + (u64)k * (g.H1 + 1);
+    r.seg_begin = ((u64)k << g.log_n) + po[h1];
+    const u64 seg_end = ((u64)k << g.log_n) + po[h1 + 1];
+    r.begin = r.seg_begin + (u64)(tile - seg_tile[lo]) * SORT_TILE;
+    r.end = r.begin + SORT_TILE < seg_end ? r.begin + SORT_TILE : seg_end;
+    return true;
+}
+
+template <class Word>
+__global__ void __launch_bounds__(256) k2_hist(const Word *__restrict__ p1, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
+                                               u32 *__restrict__ tile_hist, TabledGeom g)
+{
+    __shared__ u32 h[256];
+    const unsigned tile = blockIdx.x, tid = threadIdx.x;
+    TileRange r;
+    if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
+    h[tid] = 0;
+    __syncthreads();
+    const unsigned shift = g.log_n + 1 + g.b3;
+    const u32 mask = g.H2 - 1;
+    for (u64 i = r.begin + tid; i < r.end; i += 256) atomicAdd(&h[(u32)(p1[i] >> shift) & mask], 1u);
+    __syncthreads();
+    if (tid < g.H2) tile_hist[(u64)tile * g.H2 + tid] = h[tid];
+}
+
+// one WAVE per (segment, h2) column: exclusive prefix over the segment's tiles in place, column total to totals[s][h2]
+__global__ void __launch_bounds__(1024) k2_scan_cols(u32 *__restrict__ tile_hist, const u32 *__restrict__ seg_tile, u32 *__restrict__ totals, TabledGeom g)
+{
+    const unsigned s = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (h >= g.H2) return; // whole wave exits together
+    const unsigned t_begin = seg_tile[s], t_end = seg_tile[s + 1];
+    u32 *col = tile_hist + h;
+    u32 run = 0;
+    for (unsigned t0 = t_begin; t0 < t_end; t0 += 64) {
+        const unsigned tile = t0 + lane;
+        u32 v = tile < t_end ? col[(u64)tile * g.H2] : 0;
+        u32 inc = v;
+        for (unsigned d = 1; d < 64; d <<= 1) {
+            u32 up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (tile < t_end) col[(u64)tile * g.H2] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) totals[(u64)s * g.H2 + h] = run;
+}
+
+// one block per segment: sub_off[s][0..H2] = exclusive scan of the column totals (relative to the segment start)
+__global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals, u32 *__restrict__ sub_off, TabledGeom g)
+{
+    __shared__ u32 tot[256];
+    const unsigned s = blockIdx.x, t = threadIdx.x;
+    const u32 mine = t < g.H2 ? totals[(u64)s * g.H2 + t] : 0;
+    tot[t] = mine;
+    __syncthreads();
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        u32 v = (t >= d) ? tot[t - d] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    if (t < g.H2) sub_off[(u64)s * (g.H2 + 1) + t] = tot[t] - mine;
+    if (t == 255) sub_off[(u64)s * (g.H2 + 1) + g.H2] = tot[255];
+}
+
+// level-2 scatter: p1 words [b2][b3][sign][id] -> p2 words [b3][sign][id] (u32) grouped by b2 within the segment
+template <class Word>
+__global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const Word *__restrict__ p1, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
+                                                  const u32 *__restrict__ tile_hist, const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g)
+{
+    __shared__ u32 lstart[256], lcur[256];
+    __shared__ u64 gbase[256];
+    __shared__ u32 words[SORT_TILE];
+    __shared__ unsigned char parts_of[SORT_TILE];
+    __shared__ u32 scratch[SORT_THREADS];
+    const unsigned tile = blockIdx.x, tid = threadIdx.x;
+    TileRange r;
+    if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
+    if (tid < 256) {
+        lstart[tid] = 0;
+        lcur[tid] = 0;
+        if (tid < g.H2) gbase[tid] = r.seg_begin + sub_off[(u64)r.s * (g.H2 + 1) + tid] + tile_hist[(u64)tile * g.H2 + tid];
+    }
+    __syncthreads();
+    const unsigned shift = g.log_n + 1 + g.b3;
+    const u32 mask = g.H2 - 1;
+    const Word keep = ((Word)1 << shift) - 1;
+    for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) atomicAdd(&lstart[(u32)(p1[i] >> shift) & mask], 1u);
+    __syncthreads();
+    block_exclusive_scan(lstart, g.H2, scratch);
+    for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) {
+        const Word v = p1[i];
+        const u32 h = (u32)(v >> shift) & mask;
+        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
+        words[slot] = (u32)(v & keep);
+        parts_of[slot] = (unsigned char)h;
+    }
+    __syncthreads();
+    const u32 total = (u32)(r.end - r.begin);
+    for (u32 j = tid; j < total; j += SORT_THREADS) {
+        u32 h = parts_of[j];
+        p2[gbase[h] + (j - lstart[h])] = words[j];
+    }
+}
+
+// ---- tabled mode, level 3: merge the windows -------------------------------------------------------------------------
+// Cell q = h1 * H2 + h2 owns buckets [q << b3, (q+1) << b3).  Its entries are the W runs (k, h1, h2) of p2.
+
+__device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsigned h1, unsigned h2, const u32 *part_off, const u32 *sub_off, const TabledGeom &g)
+{
+    const unsigned s = k * g.H1 + h1;
+    const u32 *so = sub_off + (u64)s * (g.H2 + 1);
+    begin = ((u64)k << g.log_n) + part_off[(u64)k * (g.H1 + 1) + h1] + so[h2];
+    len = so[h2 + 1] - so[h2];
+}
+
+// cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b
+__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt,
+                                                       u32 *__restrict__ blk_sum, TabledGeom g)
+{
+    __shared__ u32 red[1024];
+    const unsigned q = blockIdx.x * 1024 + threadIdx.x, t = threadIdx.x;
+    u32 total = 0;
+    if (q < g.Q) {
+        const unsigned h1 = q / g.H2, h2 = q % g.H2;
+        for (unsigned k = 0; k < g.W; k++) {
+            const u32 *so = sub_off + (u64)(k * g.H1 + h1) * (g.H2 + 1);
+            total += so[h2 + 1] - so[h2];
+        }
+        cell_cnt[q] = total;
+    }
+    red[t] = total;
+    __syncthreads();
+    for (unsigned s = 512; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) blk_sum[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
+                                                const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ off,
+                                                u32 *__restrict__ sorted, TabledGeom g, unsigned NB)
+{
+    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
+    __shared__ u32 words[BS_CHUNK];
+    __shared__ unsigned char lo_of[BS_CHUNK];
+    __shared__ u32 red[SORT_THREADS];
+    __shared__ u64 rbegin[64];
+    __shared__ u32 vstart[65];
+    const unsigned q = blockIdx.x, tid = threadIdx.x;
+    const unsigned h1 = q / g.H2, h2 = q % g.H2;
+    const unsigned L = 1u << g.b3;
+    // position of the cell's first entry in the output: cells of earlier blocks + earlier cells of this block
+    {
+        const unsigned blk = q >> 10;
+        u32 v = 0;
+        for (unsigned b = tid; b < blk; b += SORT_THREADS) v += blk_sum[b];
+        const unsigned c = (blk << 10) + tid;
+        if (c < q) v += cell_cnt[c];
+        red[tid] = v;
+        __syncthreads();
+        for (unsigned s = SORT_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+    }
+    const u32 out_base = red[0];
+    if (tid == 0) {
+        u32 run = 0;
+        for (unsigned k = 0; k < g.W; k++) {
+            u64 b;
+            u32 len;
+            cell_run(b, len, k, h1, h2, part_off, sub_off, g);
+            rbegin[k] = b;
+            vstart[k] = run;
+            run += len;
+        }
+        vstart[g.W] = run;
+    }
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    const u32 N = vstart[g.W];
+    const unsigned shift = g.log_n + 1;
+    // virtual position -> (k, word)
+    auto fetch = [&](u32 p, unsigned &k) -> u32 {
+        k = 0;
+        while (p >= vstart[k + 1]) k++;
+        return p2[rbegin[k] + (p - vstart[k])];
+    };
+    for (u32 p = tid; p < N; p += SORT_THREADS) {
+        unsigned k;
+        atomicAdd(&cnt[fetch(p, k) >> shift], 1u);
+    }
+    __syncthreads();
+    u32 mine = tid < 128 ? cnt[tid] : 0;
+    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
+        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
+        __syncthreads();
+        if (tid < 128) cnt[tid] += v;
+        __syncthreads();
+    }
+    if (tid < L) {
+        u32 start = out_base + cnt[tid] - mine;
+        cur[tid] = start;
+        off[((u64)q << g.b3) + tid] = start;
+    }
+    if (q == g.Q - 1 && tid == 0) off[NB] = out_base + N;
+    __syncthreads();
+    const u32 id_mask = (1u << g.log_n) - 1;
+    for (u32 cbeg = 0; cbeg < N; cbeg += BS_CHUNK) { // N is uniform over the block: barriers are safe
+        const u32 cend = min(cbeg + BS_CHUNK, N);
+        if (tid < 128) {
+            lstart[tid] = 0;
+            lcur[tid] = 0;
+        }
+        __syncthreads();
+        for (u32 p = cbeg + tid; p < cend; p += SORT_THREADS) {
+            unsigned k;
+            atomicAdd(&lstart[fetch(p, k) >> shift], 1u);
+        }
+        __syncthreads();
+        u32 c0 = tid < 128 ? lstart[tid] : 0;
+        for (unsigned d = 1; d < 128; d <<= 1) {
+            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
+            __syncthreads();
+            if (tid < 128) lstart[tid] += v;
+            __syncthreads();
+        }
+        if (tid < 128) {
+            lstart[tid] -= c0; // exclusive
+            cnt[tid] = c0;
+        }
+        __syncthreads();
+        for (u32 p = cbeg + tid; p < cend; p += SORT_THREADS) {
+            unsigned k;
+            u32 v = fetch(p, k);
+            u32 l = v >> shift;
+            u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
+            words[slot] = (v & id_mask) | (k << g.log_n) | (((v >> g.log_n) & 1u) << 31); // row k*n + i of the tables
+            lo_of[slot] = (unsigned char)l;
+        }
+        __syncthreads();
+        for (u32 j = tid; j < cend - cbeg; j += SORT_THREADS) {
+            u32 l = lo_of[j];
+            sorted[cur[l] + (j - lstart[l])] = words[j];
+        }
+        __syncthreads();
+        if (tid < 128) cur[tid] += cnt[tid];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- host side
+
+SortGeom plain_geom(unsigned log_n, unsigned c)
+{
+    SortGeom g;
+    g.log_n = log_n;
+    g.lo_bits = std::min(std::min(7u, c - 1), 31u - log_n);
+    g.H = 1u << (c - 1 - g.lo_bits);
+    g.tiles = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
+    return g;
+}
+
+TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
+{
+    TabledGeom g{};
+    const unsigned B = plan.width[0] - 1;
+    g.log_n = log_n;
+    g.W = plan.W;
+    g.b3 = std::min(std::min(7u, 31u - log_n), B);
+    const unsigned rest = B - g.b3;
+    g.b1 = (rest + 1) / 2;
+    g.b2 = rest - g.b1;
+    g.H1 = 1u << g.b1;
+    g.H2 = 1u << g.b2;
+    g.S = g.W * g.H1;
+    g.Q = g.H1 * g.H2;
+    const u64 E = (u64)plan.W << log_n;
+    g.max_tiles2 = (unsigned)(E / SORT_TILE + g.S + 1);
+    return g;
+}
+
+bool tabled_wide_words(const TabledGeom &g) { return g.b2 + g.b3 + 1 + g.log_n > 32; }
+
+template <class Fr, class Code>
+void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan)
+{
+    hipLaunchKernelGGL((k_digits<Fr, Code>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)scalars, dig, n, plan);
+}
+
+} // namespace
+
+namespace panda {
+
+WindowPlan make_window_plan(unsigned total_bits, unsigned c)
+{
+    WindowPlan p{};
+    p.W = (total_bits + c - 1) / c;
+    const unsigned base = total_bits / p.W, rem = total_bits % p.W;
+    unsigned lo = 0;
+    for (unsigned k = 0; k < p.W; k++) {
+        p.width[k] = (unsigned char)(base + (k < rem ? 1 : 0));
+        p.lo[k] = (unsigned short)lo;
+        lo += p.width[k];
+    }
+    return p;
+}
+
+template <class Fr>
+static WindowPlan safe_plan(unsigned c)
+{
+    // BITS + 1: one spare bit for the signed-digit carry.  The top window must never carry out: its largest raw value
+    // (top bits of r - 1, plus a carry in) has to stay below half its range; widen the plan by a bit until it does.
+    constexpr int LR = Fr::L;
+    WindowPlan plan{};
+    for (unsigned total = Fr::BITS + 1;; total++) {
+        plan = make_window_plan(total, c);
+        const unsigned lo = plan.lo[plan.W - 1], m = lo >> 5, sh = lo & 31;
+        u64 top = m < (unsigned)LR ? ((u64)Fr::PW[m] >> sh) : 0;
+        if (m + 1 < (unsigned)LR) top |= (u64)Fr::PW[m + 1] << (32 - sh);
+        if (m + 2 < (unsigned)LR && sh) top |= (u64)Fr::PW[m + 2] << (64 - sh);
+        if (top + 1 < ((u64)1 << (plan.width[plan.W - 1] - 1)) || total > Fr::BITS + 8) break;
+    }
+    return plan;
+}
+
+WindowPlan make_safe_window_plan(unsigned fr, unsigned c) { return fr == 0 ? safe_plan<Bn254Fr>(c) : safe_plan<Bls377Fr>(c); }
+
+size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
+{
+    const u64 n = (u64)1 << log_n;
+    const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
+    const SortGeom g = plain_geom(log_n, c);
+    return align256(n * W * 2) + align256((size_t)W * g.tiles * g.H * 4) + 2 * align256((size_t)W * (g.H + 1) * 4) + align256((size_t)W * (NB + 1) * 4) +
+           2 * align256(n * W * 4) + 4096;
+}
+
+hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
+                          SortResult *out)
+{
+    const u64 n = (u64)1 << log_n;
+    const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
+    if (c > 16 || c < 2) return hipErrorInvalidValue;
+    const SortGeom geom = plain_geom(log_n, c);
+    if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
+    uint16_t *d_dig = (uint16_t *)arena.take(n * W * 2);
+    u32 *d_thist = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
+    u32 *d_poff = (u32 *)arena.take((size_t)W * (geom.H + 1) * 4);
+    u32 *d_ptot = (u32 *)arena.take((size_t)W * (geom.H + 1) * 4);
+    u32 *d_p1 = (u32 *)arena.take(n * W * 4);
+    u32 *d_off = (u32 *)arena.take((size_t)W * (NB + 1) * 4);
+    u32 *d_sorted = (u32 *)arena.take(n * W * 4);
+    if (!d_dig || !d_thist || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
+
+    if (fr == 0)
+        launch_digits<Bn254Fr, uint16_t>(stream, scalars, d_dig, n, plan);
+    else
+        launch_digits<Bls377Fr, uint16_t>(stream, scalars, d_dig, n, plan);
+    if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
+    hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
+    hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_ptot, geom);
+    hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, geom);
+    hipLaunchKernelGGL((k_part_scatter<uint16_t, u32>), dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
+    if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
+    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
+    out->off = d_off;
+    out->sorted = d_sorted;
+    out->lists = W;
+    out->NB = NB;
+    out->stride = n;
+    return hipGetLastError();
+}
+
+bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan)
+{
+    const unsigned c = plan.width[0];
+    if (plan.W > 32 || plan.W < 1 || c < 4 || c > 24 || log_n > 26 || log_n < 1) return false;
+    unsigned wbits = 0;
+    while ((1u << wbits) < plan.W) wbits++;
+    if (log_n + wbits > 31) return false;
+    const TabledGeom g = tabled_geom(log_n, plan);
+    return g.b1 <= 10 && g.b2 <= 8 && g.b3 <= 7 && g.S <= 16384 && g.b2 + g.b3 + 1 + log_n <= 64;
+}
+
+size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
+{
+    const u64 E = (u64)plan.W << log_n;
+    const unsigned NB = 1u << (plan.width[0] - 1);
+    const TabledGeom g = tabled_geom(log_n, plan);
+    const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
+    return align256(E * 4) + align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 8) +
+           align256((size_t)(g.S + 1) * 4) + align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
+           align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + align256((size_t)g.Q * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
+           align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
+}
+
+hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
+                           SortResult *out)
+{
+    if (!msm_sort_tabled_supported(log_n, plan)) return hipErrorInvalidValue;
+    const u64 n = (u64)1 << log_n;
+    const u64 E = (u64)plan.W << log_n;
+    const unsigned W = plan.W, NB = 1u << (plan.width[0] - 1);
+    const TabledGeom g = tabled_geom(log_n, plan);
+    const bool wide = tabled_wide_words(g);
+    SortGeom g1;
+    g1.log_n = log_n;
+    g1.lo_bits = g.b2 + g.b3;
+    g1.H = g.H1;
+    g1.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const unsigned qblocks = (g.Q + 1023) / 1024;
+
+    u32 *d_dig = (u32 *)arena.take(E * 4);
+    u32 *d_thist1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
+    u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
+    u32 *d_ptot = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
+    void *d_p1 = arena.take(E * (wide ? 8 : 4));
+    u32 *d_segtile = (u32 *)arena.take((size_t)(g.S + 1) * 4);
+    u32 *d_thist2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
+    u32 *d_tot2 = (u32 *)arena.take((size_t)g.S * g.H2 * 4);
+    u32 *d_suboff = (u32 *)arena.take((size_t)g.S * (g.H2 + 1) * 4);
+    u32 *d_p2 = (u32 *)arena.take(E * 4);
+    u32 *d_cellcnt = (u32 *)arena.take((size_t)g.Q * 4);
+    u32 *d_blksum = (u32 *)arena.take((size_t)qblocks * 4);
+    u32 *d_off = (u32 *)arena.take((size_t)(NB + 1) * 4);
+    u32 *d_sorted = (u32 *)arena.take(E * 4);
+    if (!d_dig || !d_thist1 || !d_poff || !d_ptot || !d_p1 || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum ||
+        !d_off || !d_sorted)
+        return hipErrorOutOfMemory;
+
+    if (fr == 0)
+        launch_digits<Bn254Fr, u32>(stream, scalars, d_dig, n, plan);
+    else
+        launch_digits<Bls377Fr, u32>(stream, scalars, d_dig, n, plan);
+    if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
+    // level 1, per window
+    hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);
+    hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_ptot, g1);
+    hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, g1);
+    if (wide)
+        hipLaunchKernelGGL((k_part_scatter<u32, u64>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_poff, (u64 *)d_p1, g1);
+    else
+        hipLaunchKernelGGL((k_part_scatter<u32, u32>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_poff, (u32 *)d_p1, g1);
+    // level 2, per level-1 partition
+    hipLaunchKernelGGL(k2_seg_tiles, dim3(1), dim3(SORT_THREADS), 0, stream, d_poff, d_segtile, g);
+    if (wide)
+        hipLaunchKernelGGL(k2_hist<u64>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, g);
+    else
+        hipLaunchKernelGGL(k2_hist<u32>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, g);
+    hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, g.S), dim3(1024), 0, stream, d_thist2, d_segtile, d_tot2, g);
+    hipLaunchKernelGGL(k2_offsets, dim3(g.S), dim3(256), 0, stream, d_tot2, d_suboff, g);
+    if (wide)
+        hipLaunchKernelGGL(k2_scatter<u64>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, d_suboff, d_p2, g);
+    else
+        hipLaunchKernelGGL(k2_scatter<u32>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, d_suboff, d_p2, g);
+    if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
+    // level 3, per cell
+    hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_poff, d_suboff, d_cellcnt, d_blksum, g);
+    hipLaunchKernelGGL(k3_merge, dim3(g.Q), dim3(SORT_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_cellcnt, d_blksum, d_off, d_sorted, g, NB);
+    out->off = d_off;
+    out->sorted = d_sorted;
+    out->lists = 1;
+    out->NB = NB;
+    out->stride = E;
+    return hipGetLastError();
+}
+
+} // namespace panda

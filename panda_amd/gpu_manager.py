@@ -154,6 +154,21 @@ class PandaGpuManager:
         ffi.check(ffi.load().panda_msm_register_bases(curve, C.c_void_p(d), log_n, self.exec_stream.raw), "CreateContextError")
         self._registered.append(d)
 
+    def precompute_cached_bases(self, index: int, curve: int = 0, window_bits: int = 0) -> tuple[int, int, int]:
+        """Additive: register cached base set `index` together with its window tables (panda_msm_precompute_bases).
+        Returns (tables, window_bits, device bytes held)."""
+        d = self.get_params_bases_ptr_mut(index)
+        if d is None:
+            raise PandaGpuError("BasesIndexErr")
+        nbytes = self._bases_bytes[index]
+        log_n = log_2(nbytes // _POINT_BYTES[curve])
+        lib = ffi.load()
+        ffi.check(lib.panda_msm_precompute_bases(curve, C.c_void_p(d), log_n, window_bits, self.exec_stream.raw), "CreateContextError")
+        self._registered.append(d)
+        tables, bits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
+        ffi.check(lib.panda_msm_registered_info(C.c_void_p(d), C.byref(tables), C.byref(bits), C.byref(held)), "CreateContextError")
+        return tables.value, bits.value, held.value
+
     @classmethod
     def init_msm(cls, bases_list) -> list[int]:  # wrapper.rs:122-152
         ptrs = [cls.init_msm_cached_bases(b) for b in bases_list]

@@ -530,3 +530,118 @@ def test_msm_registered_cached_bases(gm):
             out2 = pgm.panda_msm_bn254_gpu(gm, scalars, other, curve=cid)  # unregistered path still converts per call
             assert (affine_of(cid, out2) == po.expected_from_linearity(cid, 9200 + cid, scalars)).all()
     assert lib.panda_msm_unregister_bases(C.c_void_p(12345)) != 0
+
+
+def _edge_scalars(kind, n):
+    c = pyref.CURVES[0]
+    rng = np.random.default_rng(9)
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    if kind == "zeros":
+        return np.zeros((n, 8), np.uint32)
+    if kind == "ones":
+        return np.tile(mont(1), (n, 1))
+    if kind == "minus_one":
+        return np.tile(mont(c.r - 1), (n, 1))
+    if kind == "small":
+        return np.stack([mont(int(v)) for v in rng.integers(0, 1 << 16, n)])
+    if kind == "all_equal":
+        return np.tile(po.gen_scalars(po.F_BN254_FR, 77, 1), (n, 1))
+    if kind == "half_zero":
+        s = po.gen_scalars(po.F_BN254_FR, 78, n)
+        s[::2] = 0
+        return s
+    return np.stack([mont((1 << 253) + int(v)) for v in rng.integers(0, 1 << 30, n)])
+
+
+@pytest.mark.parametrize("cid,k,wbits", [(0, 10, 10), (0, 12, 12), (0, 13, 16), (0, 13, 0), (0, 14, 18), (0, 16, 0), (1, 12, 13), (1, 13, 17)])
+def test_msm_precomputed_tables(gm, cid, k, wbits):
+    """panda_msm_precompute_bases: window tables 2^lo[k]*P, one shared bucket space, three-level sort.
+    Same group element as the plain path for several table geometries; other buffers are unaffected."""
+    n = 1 << k
+    bases = po.gen_bases(cid, 9400 + k, n)
+    other = po.gen_bases(cid, 9500 + k, n)
+    idx = gm.add_cached_bases(bases)
+    tables, bits, held = gm.precompute_cached_bases(idx, curve=cid, window_bits=wbits)
+    assert tables >= 2 and (wbits == 0 or 0 < bits <= wbits) and held == tables * n * 2 * po.LC_Q[cid] * 4
+    for rep in range(2):
+        scalars = po.gen_scalars(po.FR_OF[cid], 9600 + rep, n)
+        keep = scalars.copy()
+        coord = pgm.PROJECTIVE if rep else pgm.JACOBIAN
+        gm.set_config(coord)
+        try:
+            out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=cid)
+        finally:
+            gm.set_config(pgm.JACOBIAN)
+        assert (affine_of(cid, out, coord) == po.expected_from_linearity(cid, 9400 + k, scalars)).all()
+        assert (scalars == keep).all()
+    out2 = pgm.panda_msm_bn254_gpu(gm, scalars, other, curve=cid)
+    assert (affine_of(cid, out2) == po.expected_from_linearity(cid, 9500 + k, scalars)).all()
+
+
+@pytest.mark.parametrize("kind", EDGE_SETS)
+def test_msm_precomputed_tables_edge_scalars(gm, kind):
+    n = 1 << 12
+    bases = po.gen_bases(0, 55, n)
+    idx = gm.add_cached_bases(bases)
+    gm.precompute_cached_bases(idx, curve=0, window_bits=14)
+    scalars = _edge_scalars(kind, n)
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.expected_from_linearity(0, 55, scalars)).all()
+    if kind == "zeros":
+        assert not out.view(np.uint32)[16:].any()  # Z == 0: the identity
+
+
+def test_msm_precomputed_tables_degenerate_bases(gm):
+    """identity rows stay identity in every table; repeated points and P, -P pairs meet in the same bucket."""
+    n = 1 << 10
+    lc = 8
+    bases = po.gen_bases(0, 66, n)
+    scalars = po.gen_scalars(po.F_BN254_FR, 67, n)
+    bases[3::7, :lc] = 0
+    bases[100:200] = bases[100]
+    bases[301] = bases[300]
+    bases[301, lc:] = po.f_vec(0, po.OP_SUB, np.zeros((1, lc), np.uint32), bases[300:301, lc:])[0]
+    scalars[301] = scalars[300]
+    scalars[100:150] = scalars[100]
+    idx = gm.add_cached_bases(bases)
+    gm.precompute_cached_bases(idx, curve=0, window_bits=11)
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.msm_affine(0, bases, scalars, window_bits=9)).all()
+
+
+def _msm_precomputed_on_device(gm, cid, k, wbits, seed_b, seed_s):
+    n = 1 << k
+    lib = ffi.load()
+    db = DeviceBuffer(n * 2 * po.LC_Q[cid] * 4)
+    ds = DeviceBuffer(n * 32)
+    dr = DeviceBuffer(3 * po.LC_Q[cid] * 4)
+    ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(cid, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_msm_precompute_bases(cid, db.ptr, k, wbits, gm.exec_stream.raw), "precompute")
+    tables, bits = C.c_uint(0), C.c_uint(0)
+    ffi.check(lib.panda_msm_registered_info(db.ptr, C.byref(tables), C.byref(bits), None), "info")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    fn = lib.panda_msm_execute_bn254 if cid == 0 else lib.panda_msm_execute_bls12_377
+    ffi.check(fn(cfg), "msm")
+    out = dr.to_host()
+    scalars = ds.to_host().reshape(n, 8)
+    ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
+    for d in (db, ds, dr):
+        d.free()
+    return out, scalars, tables.value, bits.value
+
+
+def test_msm_precomputed_tables_wide_words_2_18(gm):
+    """2^18 points with 22-bit windows: 2^21 shared buckets, 64-bit level-1 sort words."""
+    out, scalars, tables, bits = _msm_precomputed_on_device(gm, 0, 18, 22, 0x70616E6461 ^ 7, 0x5CA1A7)
+    assert bits == 22 and tables == 12
+    assert (po.to_affine(0, out) == po.expected_from_linearity(0, 0x70616E6461 ^ 7, scalars)).all()
+
+
+@pytest.mark.parametrize("cid,k", [(0, 20), (0, 24), (1, 22)])
+def test_msm_precomputed_tables_baseline_sizes(gm, cid, k):
+    """BASELINE configs 2 (BN254 2^20, cached bases) and the headline 2^24 with the built-in table policy; linearity."""
+    seed_b = 0x70616E6461 ^ (8 + k)
+    out, scalars, tables, bits = _msm_precomputed_on_device(gm, cid, k, 0, seed_b, 0x5CA1A8 + k)
+    assert tables >= 2
+    assert (po.to_affine(cid, out) == po.expected_from_linearity(cid, seed_b, scalars)).all()
