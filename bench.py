@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the contract) or gloo (rehearsal of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-register", action="store_true", help="do not register the cached bases (plain drop-in call path)")
+    ap.add_argument("--no-tables", action="store_true", help="register the cached bases without precomputed window tables")
     return ap.parse_args()
 
 
@@ -107,10 +108,24 @@ def main():
     first = rank * n  # this rank's base range of the virtual N * 2^log_n problem
     ffi.check(lib.panda_gen_bases(0, 0x70616E6461, first, n, bases.data_ptr(), pstream), "gen_bases")
     ffi.check(lib.panda_gen_scalars(0, 0x70616E6461 ^ 0xFFFF, first, n, scalars.data_ptr(), pstream), "gen_scalars")
+    bases_mode = "resident, plain pointer"
     if not args.no_register:
         # "cached bases" (BASELINE config): the base set stays on the device across MSMs and is registered once, so the
-        # library keeps its radix-converted copy instead of re-deriving it in every call
-        ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
+        # library keeps its radix-converted copy -- and, unless --no-tables, the window tables 2^lo[k]*P built from it --
+        # instead of re-deriving them in every call.  Built before the timed region; depends on the bases only.
+        t_reg = time.perf_counter()
+        if args.no_tables:
+            ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
+        else:
+            ffi.check(lib.panda_msm_precompute_bases(0, bases.data_ptr(), log_n, 0, pstream), "precompute_bases")
+        t_reg = time.perf_counter() - t_reg
+        tables, wbits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
+        ffi.check(lib.panda_msm_registered_info(bases.data_ptr(), C.byref(tables), C.byref(wbits), C.byref(held)), "registered_info")
+        if args.no_tables:
+            bases_mode = "cached: resident and registered (panda_msm_register_bases)"
+        else:
+            bases_mode = (f"cached: resident, registered with {tables.value} precomputed window tables of {wbits.value}-bit windows "
+                          f"(panda_msm_precompute_bases: {held.value / 2**30:.1f} GiB, built once in {t_reg:.2f} s, outside the timed region)")
     cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), pstream, bases.data_ptr(), scalars.data_ptr(), result.data_ptr(), log_n, ffi.JACOBIAN)
 
     phase = (C.c_float * 8)()
@@ -178,7 +193,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BN254 MSM 2^{log_n} points per GPU, Jacobian output, bases and scalars resident in HBM",
                        "curve": "bn254", "log_points_per_gpu": log_n,
-                       "bases": "resident, plain pointer" if args.no_register else "cached: resident and registered (panda_msm_register_bases)", "sharding": f"base-range x{world}" if world > 1 else "none",
+                       "bases": bases_mode, "sharding": f"base-range x{world}" if world > 1 else "none",
                        "exchange": f"all-gather of 96 B partials ({'RCCL' if args.dist_backend == 'nccl' else args.dist_backend}) + host point additions" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -187,6 +202,8 @@ def main():
         }
         if world == 1:
             out["pcie_inclusive"] = pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n)
+            if not args.no_register and not args.no_tables:
+                out["without_tables"] = without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, max(2, args.steps // 2))
         if not args.no_ntt:
             out["ntt"] = ntt_figure(lib, ffi, torch, dev, pstream)
         if world == 1 and not args.no_cpu_baseline:
@@ -195,6 +212,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, steps) -> dict:
+    """The same call with the bases registered but no window tables (run after the timed region, for comparison)."""
+    ffi.check(lib.panda_msm_unregister_bases(bases.data_ptr()), "unregister_bases")
+    ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
+    ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
+    fence()
+    dt = (time.perf_counter() - t0) / steps
+    phase = (C.c_float * 8)()
+    lib.panda_msm_last_phase_ms(phase)
+    return {"ms_per_step": dt * 1e3, "value": (1 << log_n) / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": phase[3]}
 
 
 def pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n) -> dict:

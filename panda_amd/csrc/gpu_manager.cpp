@@ -111,6 +111,15 @@ PandaGpuError PandaGpuManager::register_cached_bases(size_t index, uint32_t log_
     return PandaGpuError::Ok;
 }
 
+PandaGpuError PandaGpuManager::precompute_cached_bases(size_t index, uint32_t log_n, uint32_t window_bits)
+{
+    void *d = get_params_bases_ptr_mut(index);
+    if (!d) return PandaGpuError::BasesIndexErr;
+    if (panda_msm_precompute_bases(0, d, log_n, window_bits, exec_stream_) != 0) return PandaGpuError::CreateContextError;
+    registered_bases.push_back(d);
+    return PandaGpuError::Ok;
+}
+
 PandaGpuError PandaGpuManager::wait_h2d() const
 {
     Event ev;

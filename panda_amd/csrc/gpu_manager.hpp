@@ -85,6 +85,8 @@ class PandaGpuManager {
     static PandaGpuError init_ntt(Bytes omega);                                          // wrapper.rs:199-210
     // additive: let the library keep the radix-converted copy of cached base set `index` (2^log_n points) between calls
     PandaGpuError register_cached_bases(size_t index, uint32_t log_n);
+    // additive: the same plus precomputed window tables (panda_msm_precompute_bases); window_bits 0 = built-in policy
+    PandaGpuError precompute_cached_bases(size_t index, uint32_t log_n, uint32_t window_bits = 0);
 
     void set_config(panda_msm_result_coordinate_type t) { msm_result_coordinate_type_ = t; } // wrapper.rs:212-214
     panda_mem_pool get_mem_pool() const { return mem_pool_; }

@@ -23,8 +23,8 @@
 //   k_bucket_sort     level 2: one workgroup per partition ranks the lo bits in LDS -> bucket offsets + point-id lists
 //   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
 //   k_fixup           merge bucket pieces that straddle chunks
-//   k_reduce_groups   4 buckets -> one weighted partial
-//   k_tree_reduce     partials -> one point per window
+//   k_reduce_groups   running sums over groups of buckets
+//   k_bit_sums/finish weighted sum of the group sums, bit by bit -> one point per window
 //   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743), output conversion
 #include <algorithm>
 #include <mutex>
@@ -378,30 +378,17 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
     }
 }
 
-// k * p for a small scalar k (double-and-add from the top bit)
+// ---- bucket reduction: sum over b of (b+1) * B_b per list ------------------------------------------------------------
+// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420 (~240 mulmods per bucket) with
+//   k_reduce_groups  thread g takes `group` buckets: running sums from the top give S_g = sum B_j and
+//                    T_g = sum (j+1) B_j (j local) -- two additions per bucket.  The list's value is
+//                    sum_g T_g + group * sum_g g * S_g.
+//   k_bit_sums       the weighted sum over g is taken bit by bit: slot 1+j adds up the S_g whose index has bit j
+//                    set, slot 0 adds up all T_g; plain tree reductions, no scalar multiplications.
+//   k_bit_finish     slot 1+j is doubled (j + log2 group) times;  k_slot_sum adds the slots up.
 template <class F>
-__device__ __forceinline__ void xyzz_mul_small(Xyzz<F> &r, const Xyzz<F> &p, u32 k)
-{
-    Xyzz<F> acc, d;
-    xyzz_set_identity(acc);
-    if (k == 0 || xyzz_is_identity(p)) {
-        r = acc;
-        return;
-    }
-    int top = 31 - __clz(k);
-    for (int bit = top; bit >= 0; bit--) {
-        xyzz_dbl(d, acc);
-        acc = d;
-        if ((k >> bit) & 1) xyzz_add(acc, p);
-    }
-    r = acc;
-}
-
-// thread (w, g): buckets b = g*group .. g*group+group-1, weights b+1.
-//   running sums from the top give S = sum B_j and T = sum (j+1) B_j (j local); the partial is T + (g*group) * S.
-// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420.
-template <class F>
-__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ out, unsigned NB, unsigned groups, unsigned group)
+__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ gS, u32 *__restrict__ gT, unsigned NB,
+                                                       unsigned groups, unsigned group)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
@@ -420,24 +407,36 @@ __global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ b
         }
         xyzz_add(sum, run);
     }
-    xyzz_mul_small(q, run, g * group);
-    xyzz_add(sum, q);
-    store_xyzz<F>(out + ((u64)w * groups + g) * PW, sum);
+    store_xyzz<F>(gS + ((u64)w * groups + g) * PW, run);
+    store_xyzz<F>(gT + ((u64)w * groups + g) * PW, sum);
 }
 
-// block b of window w sums in[w][b*per .. b*per+per) -> out[w][b]
+// block (blk, slot, w): partial sum of its share of the slot's operands -> out[w][slot][blk]
 template <class F>
-__global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned count, unsigned per)
+__global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, const u32 *__restrict__ gT, u32 *__restrict__ out, unsigned groups, unsigned slots,
+                                                  unsigned nblk)
 {
     constexpr int PW = 4 * F::N;
     __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned w = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-    const unsigned begin = blk * per, end = min(begin + per, count);
+    const unsigned blk = blockIdx.x, slot = blockIdx.y, w = blockIdx.z, t = threadIdx.x;
     Xyzz<F> acc, q;
     xyzz_set_identity(acc);
-    for (unsigned i = begin + t; i < end; i += 256) {
-        load_xyzz<F>(q, in + ((u64)w * count + i) * PW);
-        xyzz_add(acc, q);
+    if (slot == 0) {
+        const u32 *src = gT + (u64)w * groups * PW;
+        for (unsigned g = blk * 256 + t; g < groups; g += nblk * 256) {
+            load_xyzz<F>(q, src + (u64)g * PW);
+            xyzz_add(acc, q);
+        }
+    } else {
+        const unsigned j = slot - 1;
+        const u32 *src = gS + (u64)w * groups * PW;
+        const u32 low = (1u << j) - 1;
+        for (unsigned i = blk * 256 + t;; i += nblk * 256) { // i-th index with bit j set
+            const unsigned g = ((i & ~low) << 1) | (1u << j) | (i & low);
+            if (g >= groups) break; // g grows with i
+            load_xyzz<F>(q, src + (u64)g * PW);
+            xyzz_add(acc, q);
+        }
     }
     store_xyzz<F>(lds + t * PW, acc);
     __syncthreads();
@@ -449,7 +448,64 @@ __global__ void __launch_bounds__(256) k_tree_reduce(const u32 *__restrict__ in,
         }
         __syncthreads();
     }
-    if (t == 0) store_xyzz<F>(out + ((u64)w * gridDim.x + blk) * PW, acc);
+    if (t == 0) store_xyzz<F>(out + (((u64)w * slots + slot) * nblk + blk) * PW, acc);
+}
+
+// block (slot, w), 64 threads: tree over the slot's nblk partials, then slot 1+j is doubled (j + log2 group) times
+template <class F>
+__global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots, unsigned nblk, unsigned log_group)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
+    const unsigned slot = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    Xyzz<F> acc, q;
+    xyzz_set_identity(acc);
+    for (unsigned b = t; b < nblk; b += 64) {
+        load_xyzz<F>(q, in + (((u64)w * slots + slot) * nblk + b) * PW);
+        xyzz_add(acc, q);
+    }
+    store_xyzz<F>(lds + t * PW, acc);
+    __syncthreads();
+    for (unsigned s = 32; s > 0; s >>= 1) {
+        if (t < s && t + s < nblk) { // partials beyond nblk are the identity
+            load_xyzz<F>(q, lds + (t + s) * PW);
+            xyzz_add(acc, q);
+            store_xyzz<F>(lds + t * PW, acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const unsigned doublings = slot ? (slot - 1 + log_group) : 0;
+#pragma unroll 1
+        for (unsigned d = 0; d < doublings; d++) {
+            xyzz_dbl(q, acc);
+            acc = q;
+        }
+        store_xyzz<F>(out + ((u64)w * slots + slot) * PW, acc);
+    }
+}
+
+// block w, 64 threads: sum of the list's slots -> one point per list
+template <class F>
+__global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
+    const unsigned w = blockIdx.x, t = threadIdx.x;
+    Xyzz<F> acc, q;
+    xyzz_set_identity(acc);
+    if (t < slots) load_xyzz<F>(acc, in + ((u64)w * slots + t) * PW);
+    store_xyzz<F>(lds + t * PW, acc);
+    __syncthreads();
+    for (unsigned s = 32; s > 0; s >>= 1) {
+        if (t < s && t + s < slots) {
+            load_xyzz<F>(q, lds + (t + s) * PW);
+            xyzz_add(acc, q);
+            store_xyzz<F>(lds + t * PW, acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz<F>(out + (u64)w * PW, acc);
 }
 
 // Precomputed window tables for cached bases (the reference left the idea as a stub,
@@ -597,11 +653,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const unsigned lg = floor_log2(stride);
     const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16)); // sorted entries per accumulate thread
     const unsigned chunks = (unsigned)((stride + K - 1) / K);
-    const unsigned group = g_reduce_group ? g_reduce_group : (NB >= (1u << 18) ? 16u : 4u); // buckets per k_reduce_groups thread
+    unsigned log_group = NB >= (1u << 18) ? 3u : 2u; // log2 of the buckets per k_reduce_groups thread
+    if (g_reduce_group) log_group = floor_log2(g_reduce_group);
+    const unsigned group = 1u << log_group;
     const unsigned groups = (NB + group - 1) / group;
-    const unsigned lvl1_cap = lists == 1 ? 512u : 64u;
-    const unsigned lvl1 = std::min((groups + 255) / 256, lvl1_cap); // blocks in the first tree level
-    const unsigned per1 = (groups + lvl1 - 1) / lvl1;
+    unsigned slots = 1; // slot 0: the T_g; slot 1+j: the S_g whose index has bit j set
+    while ((1u << (slots - 1)) < groups) slots++;
+    const unsigned nblk = std::min(std::max(groups / 2048u, 1u), 64u); // blocks per slot in k_bit_sums
+    if (slots > 64) return hipErrorInvalidValue;
 
     // ---- scratch
     const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
@@ -609,22 +668,25 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
     const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
     const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
-    const size_t sz_l1 = panda::align256((size_t)lists * lvl1 * PW * 4);
+    const size_t sz_l1 = panda::align256((size_t)lists * slots * nblk * PW * 4);
     const size_t sz_win = panda::align256((size_t)lists * PW * 4);
+    const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
     const unsigned long_cap = chunks / LONG_SPAN + 2;
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
     const size_t sz_llist = panda::align256((size_t)lists * long_cap * 3 * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_sort + sz_bacc + sz_parts + sz_gsum + sz_l1 + sz_win + sz_lcount + sz_llist + 8192));
+    PANDA_TRY(arena.reserve(sz_bases + sz_sort + sz_bacc + sz_parts + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + sz_lcount + sz_llist + 8192));
     const u32 *d_bases = registered ? (const u32 *)reg.converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
     u32 *d_parts = (u32 *)arena.take(sz_parts);
     u32 *d_gsum = (u32 *)arena.take(sz_gsum);
+    u32 *d_gtsum = (u32 *)arena.take(sz_gsum);
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_win = (u32 *)arena.take(sz_win);
+    u32 *d_slots = (u32 *)arena.take(sz_slots);
     u32 *d_lcount = (u32 *)arena.take(sz_lcount);
     u32 *d_llist = (u32 *)arena.take(sz_llist);
-    if (!d_bases || !d_bacc || !d_parts || !d_gsum || !d_l1 || !d_win || !d_lcount || !d_llist) return hipErrorOutOfMemory;
+    if (!d_bases || !d_bacc || !d_parts || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots || !d_lcount || !d_llist) return hipErrorOutOfMemory;
 
     struct PhaseEvents { // destroyed on every exit path
         hipEvent_t ev[8] = {};
@@ -658,9 +720,10 @@ hipError_t msm_execute(const panda_msm_configuration &cfg)
                        long_cap);
     hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
     PANDA_TRY(mark(5));
-    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, NB, groups, group);
-    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(lvl1, lists), dim3(256), 0, stream, d_gsum, d_l1, groups, per1);
-    hipLaunchKernelGGL(k_tree_reduce<Fq>, dim3(1, lists), dim3(256), 0, stream, d_l1, d_win, lvl1, lvl1);
+    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
+    hipLaunchKernelGGL(k_bit_sums<Fq>, dim3(nblk, slots, lists), dim3(256), 0, stream, d_gsum, d_gtsum, d_l1, groups, slots, nblk);
+    hipLaunchKernelGGL(k_bit_finish<Fq>, dim3(slots, lists), dim3(64), 0, stream, d_l1, d_slots, slots, nblk, log_group);
+    hipLaunchKernelGGL(k_slot_sum<Fq>, dim3(lists), dim3(64), 0, stream, d_slots, d_win, slots);
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
 

@@ -12,6 +12,7 @@
 //                key is three digits deep: level 1 (per window), level 2 (per level-1 partition, ragged tiles),
 //                level 3 (one workgroup per (hi, mid) cell merges the W per-window runs and ranks the low bits).
 #include <algorithm>
+#include <cstdlib>
 
 #include "fe29.h"
 #include "msm_sort.h"
@@ -122,23 +123,24 @@ __global__ void __launch_bounds__(256) k_part_hist(const Code *__restrict__ dig,
     for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
 }
 
-// tile_hist -> exclusive prefix over tiles (in place), one WAVE per (window, partition) column: 64 tiles per step with a
-// shuffle scan instead of one dependent load per tile; column totals go to `totals`
-__global__ void __launch_bounds__(1024) k_part_scan_cols(u32 *__restrict__ tile_hist, u32 *__restrict__ totals, SortGeom g)
+// tile_hist -> exclusive prefix over tiles (tile_pref), one WAVE per (window, partition) column: 64 tiles per step with a
+// shuffle scan instead of one dependent load per tile; column totals go to `totals`.  tile_hist keeps the counts: the
+// scatter kernels start from them instead of counting their tile again.
+__global__ void __launch_bounds__(1024) k_part_scan_cols(const u32 *__restrict__ tile_hist, u32 *__restrict__ tile_pref, u32 *__restrict__ totals, SortGeom g)
 {
     const unsigned w = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
     if (h >= g.H) return; // whole wave exits together
-    u32 *col = tile_hist + (u64)w * g.tiles * g.H + h;
+    const u64 col = (u64)w * g.tiles * g.H + h;
     u32 run = 0;
     for (unsigned t0 = 0; t0 < g.tiles; t0 += 64) {
         const unsigned tile = t0 + lane;
-        u32 v = tile < g.tiles ? col[(u64)tile * g.H] : 0;
+        u32 v = tile < g.tiles ? tile_hist[col + (u64)tile * g.H] : 0;
         u32 inc = v;
         for (unsigned d = 1; d < 64; d <<= 1) {
             u32 up = __shfl_up(inc, d, 64);
             if (lane >= d) inc += up;
         }
-        if (tile < g.tiles) col[(u64)tile * g.H] = run + inc - v;
+        if (tile < g.tiles) tile_pref[col + (u64)tile * g.H] = run + inc - v;
         run += __shfl(inc, 63, 64);
     }
     if (lane == 0) totals[(u64)w * g.H + h] = run;
@@ -196,8 +198,8 @@ __device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32
 // The tile is first grouped by partition in LDS (local counting sort), then written out linearly, so that a wave
 // stores runs of consecutive addresses instead of 64 unrelated words.
 template <class Code, class Word>
-__global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ part_off,
-                                                      Word *__restrict__ p1, SortGeom g)
+__global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
+                                                      const u32 *__restrict__ part_off, Word *__restrict__ p1, SortGeom g)
 {
     typedef CodeTraits<Code> CT;
     __shared__ u32 lstart[MAX_PARTS]; // local start of each partition's run in the staging buffer
@@ -207,12 +209,12 @@ __global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__res
     __shared__ uint16_t parts_of[SORT_TILE];
     __shared__ u32 scratch[SORT_THREADS];
     const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const u32 *base = tile_hist + ((u64)w * g.tiles + tile) * g.H;
+    const u64 row = ((u64)w * g.tiles + tile) * g.H;
     const u32 *po = part_off + (u64)w * (g.H + 1);
     for (unsigned i = tid; i < g.H; i += SORT_THREADS) {
-        lstart[i] = 0;
+        lstart[i] = tile_hist[row + i]; // this tile's count, turned into a local offset by the scan below
         lcur[i] = 0;
-        gbase[i] = po[i] + base[i];
+        gbase[i] = po[i] + tile_pref[row + i];
     }
     __syncthreads();
     const u64 n = (u64)1 << g.log_n;
@@ -220,11 +222,6 @@ __global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__res
     Word *pw = p1 + ((u64)w << g.log_n);
     const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
     const u32 lo_mask = (1u << g.lo_bits) - 1;
-    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
-        u32 code = dw[i];
-        if (code != CT::ZERO) atomicAdd(&lstart[(code & CT::MAG) >> g.lo_bits], 1u);
-    }
-    __syncthreads();
     block_exclusive_scan(lstart, g.H, scratch);
     for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
         u32 code = dw[i];
@@ -311,6 +308,44 @@ __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restr
         __syncthreads();
         if (tid < 128) cur[tid] += cnt[tid];
         __syncthreads();
+    }
+}
+
+// variant without the LDS staging: one counting pass, then every word goes straight to its slot (a partition's
+// output range is written by this workgroup alone)
+__global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort_direct(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
+                                                            u32 *__restrict__ sorted, SortGeom g, unsigned NB)
+{
+    __shared__ u32 cnt[128], cur[128];
+    const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+    const unsigned L = 1u << g.lo_bits;
+    const u32 ps = part_off[(u64)w * (g.H + 1) + h], pe = part_off[(u64)w * (g.H + 1) + h + 1];
+    const u32 *pw = p1 + ((u64)w << g.log_n);
+    u32 *sw = sorted + ((u64)w << g.log_n);
+    const unsigned shift = g.log_n + 1;
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    for (u32 j = ps + tid; j < pe; j += SORT_THREADS) atomicAdd(&cnt[pw[j] >> shift], 1u);
+    __syncthreads();
+    u32 mine = tid < 128 ? cnt[tid] : 0;
+    for (unsigned d = 1; d < 128; d <<= 1) {
+        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
+        __syncthreads();
+        if (tid < 128) cnt[tid] += v;
+        __syncthreads();
+    }
+    if (tid < L) {
+        u32 start = ps + cnt[tid] - mine;
+        cur[tid] = start;
+        off[(u64)w * (NB + 1) + ((u64)h << g.lo_bits) + tid] = start;
+    }
+    if (h == g.H - 1 && tid == 0) off[(u64)w * (NB + 1) + NB] = pe;
+    __syncthreads();
+    const u32 id_mask = (1u << g.log_n) - 1;
+    for (u32 j = ps + tid; j < pe; j += SORT_THREADS) {
+        const u32 v = pw[j];
+        const u32 slot = atomicAdd(&cur[v >> shift], 1u);
+        sw[slot] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
     }
 }
 
@@ -406,23 +441,23 @@ __global__ void __launch_bounds__(256) k2_hist(const Word *__restrict__ p1, cons
     if (tid < g.H2) tile_hist[(u64)tile * g.H2 + tid] = h[tid];
 }
 
-// one WAVE per (segment, h2) column: exclusive prefix over the segment's tiles in place, column total to totals[s][h2]
-__global__ void __launch_bounds__(1024) k2_scan_cols(u32 *__restrict__ tile_hist, const u32 *__restrict__ seg_tile, u32 *__restrict__ totals, TabledGeom g)
+// one WAVE per (segment, h2) column: exclusive prefix over the segment's tiles (tile_pref), column total to totals[s][h2]
+__global__ void __launch_bounds__(1024) k2_scan_cols(const u32 *__restrict__ tile_hist, u32 *__restrict__ tile_pref, const u32 *__restrict__ seg_tile,
+                                                     u32 *__restrict__ totals, TabledGeom g)
 {
     const unsigned s = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
     if (h >= g.H2) return; // whole wave exits together
     const unsigned t_begin = seg_tile[s], t_end = seg_tile[s + 1];
-    u32 *col = tile_hist + h;
     u32 run = 0;
     for (unsigned t0 = t_begin; t0 < t_end; t0 += 64) {
         const unsigned tile = t0 + lane;
-        u32 v = tile < t_end ? col[(u64)tile * g.H2] : 0;
+        u32 v = tile < t_end ? tile_hist[(u64)tile * g.H2 + h] : 0;
         u32 inc = v;
         for (unsigned d = 1; d < 64; d <<= 1) {
             u32 up = __shfl_up(inc, d, 64);
             if (lane >= d) inc += up;
         }
-        if (tile < t_end) col[(u64)tile * g.H2] = run + inc - v;
+        if (tile < t_end) tile_pref[(u64)tile * g.H2 + h] = run + inc - v;
         run += __shfl(inc, 63, 64);
     }
     if (lane == 0) totals[(u64)s * g.H2 + h] = run;
@@ -449,7 +484,8 @@ __global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals
 // level-2 scatter: p1 words [b2][b3][sign][id] -> p2 words [b3][sign][id] (u32) grouped by b2 within the segment
 template <class Word>
 __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const Word *__restrict__ p1, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
-                                                  const u32 *__restrict__ tile_hist, const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g)
+                                                  const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref, const u32 *__restrict__ sub_off,
+                                                  u32 *__restrict__ p2, TabledGeom g)
 {
     __shared__ u32 lstart[256], lcur[256];
     __shared__ u64 gbase[256];
@@ -460,16 +496,14 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const Word *__restric
     TileRange r;
     if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
     if (tid < 256) {
-        lstart[tid] = 0;
+        lstart[tid] = tid < g.H2 ? tile_hist[(u64)tile * g.H2 + tid] : 0;
         lcur[tid] = 0;
-        if (tid < g.H2) gbase[tid] = r.seg_begin + sub_off[(u64)r.s * (g.H2 + 1) + tid] + tile_hist[(u64)tile * g.H2 + tid];
+        if (tid < g.H2) gbase[tid] = r.seg_begin + sub_off[(u64)r.s * (g.H2 + 1) + tid] + tile_pref[(u64)tile * g.H2 + tid];
     }
     __syncthreads();
     const unsigned shift = g.log_n + 1 + g.b3;
     const u32 mask = g.H2 - 1;
     const Word keep = ((Word)1 << shift) - 1;
-    for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) atomicAdd(&lstart[(u32)(p1[i] >> shift) & mask], 1u);
-    __syncthreads();
     block_exclusive_scan(lstart, g.H2, scratch);
     for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) {
         const Word v = p1[i];
@@ -498,8 +532,7 @@ __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsig
 }
 
 // cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b
-__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt,
-                                                       u32 *__restrict__ blk_sum, TabledGeom g)
+__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g)
 {
     __shared__ u32 red[1024];
     const unsigned q = blockIdx.x * 1024 + threadIdx.x, t = threadIdx.x;
@@ -521,63 +554,127 @@ __global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ p
     if (t == 0) blk_sum[blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
-                                                const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ off,
-                                                u32 *__restrict__ sorted, TabledGeom g, unsigned NB)
+// cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block
+__global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ cell_off, TabledGeom g)
 {
-    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
-    __shared__ u32 words[BS_CHUNK];
-    __shared__ unsigned char lo_of[BS_CHUNK];
-    __shared__ u32 red[SORT_THREADS];
+    __shared__ u32 red[1024];
+    __shared__ u32 sc[1024];
+    const unsigned blk = blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
+    u32 v = 0;
+    for (unsigned b = t; b < blk; b += 1024) v += blk_sum[b];
+    red[t] = v;
+    const u32 mine = q < g.Q ? cell_cnt[q] : 0;
+    sc[t] = mine;
+    __syncthreads();
+    for (unsigned s = 512; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 u = (t >= d) ? sc[t - d] : 0;
+        __syncthreads();
+        sc[t] += u;
+        __syncthreads();
+    }
+    if (q < g.Q) cell_off[q] = red[0] + sc[t] - mine;
+    if (q == g.Q - 1) cell_off[g.Q] = red[0] + sc[t];
+}
+
+constexpr unsigned K3_THREADS = 1024;
+constexpr unsigned K3_PER = 12;                     // words a thread keeps in registers
+constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once
+
+__global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
+                                              const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB)
+{
+    __shared__ u32 cnt[128], cur[128];
+    __shared__ u32 outbuf[K3_CAP];
     __shared__ u64 rbegin[64];
+    __shared__ u32 rlen[64];
     __shared__ u32 vstart[65];
     const unsigned q = blockIdx.x, tid = threadIdx.x;
     const unsigned h1 = q / g.H2, h2 = q % g.H2;
     const unsigned L = 1u << g.b3;
-    // position of the cell's first entry in the output: cells of earlier blocks + earlier cells of this block
-    {
-        const unsigned blk = q >> 10;
-        u32 v = 0;
-        for (unsigned b = tid; b < blk; b += SORT_THREADS) v += blk_sum[b];
-        const unsigned c = (blk << 10) + tid;
-        if (c < q) v += cell_cnt[c];
-        red[tid] = v;
-        __syncthreads();
-        for (unsigned s = SORT_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
-    }
-    const u32 out_base = red[0];
-    if (tid == 0) {
-        u32 run = 0;
-        for (unsigned k = 0; k < g.W; k++) {
-            u64 b;
-            u32 len;
-            cell_run(b, len, k, h1, h2, part_off, sub_off, g);
-            rbegin[k] = b;
-            vstart[k] = run;
-            run += len;
-        }
-        vstart[g.W] = run;
+    const u32 out_base = cell_off[q];
+    if (tid < g.W) {
+        u64 b;
+        u32 len;
+        cell_run(b, len, tid, h1, h2, part_off, sub_off, g);
+        rbegin[tid] = b;
+        rlen[tid] = len;
     }
     if (tid < 128) cnt[tid] = 0;
     __syncthreads();
-    const u32 N = vstart[g.W];
+    if (tid == 0) {
+        u32 run = 0;
+        for (unsigned k = 0; k < g.W; k++) {
+            vstart[k] = run;
+            run += rlen[k];
+        }
+        vstart[g.W] = run;
+    }
+    __syncthreads();
+    const u32 N = vstart[g.W]; // uniform over the block
     const unsigned shift = g.log_n + 1;
-    // virtual position -> (k, word)
-    auto fetch = [&](u32 p, unsigned &k) -> u32 {
-        k = 0;
-        while (p >= vstart[k + 1]) k++;
-        return p2[rbegin[k] + (p - vstart[k])];
+    const u32 id_mask = (1u << g.log_n) - 1;
+    // virtual position in the concatenation of the W runs -> window
+    auto window_of = [&](u32 p) -> unsigned { // branch-free: the W - 1 broadcast reads pipeline
+        unsigned k = 0;
+        for (unsigned j = 1; j < g.W; j++) k += p >= vstart[j] ? 1u : 0u;
+        return k;
     };
-    for (u32 p = tid; p < N; p += SORT_THREADS) {
-        unsigned k;
-        atomicAdd(&cnt[fetch(p, k) >> shift], 1u);
+    // final word: row k*n + i of the tables, bit 31 = negate
+    auto final_word = [&](u32 v, unsigned k) -> u32 { return (v & id_mask) | (k << g.log_n) | (((v >> g.log_n) & 1u) << 31); };
+
+    if (N <= K3_CAP) {
+        // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
+        // (the cell's buckets are adjacent in the output)
+        u32 word[K3_PER];
+        unsigned char lo[K3_PER];
+#pragma unroll
+        for (unsigned j = 0; j < K3_PER; j++) {
+            const u32 p = tid + j * K3_THREADS;
+            if (p < N) {
+                const unsigned k = window_of(p);
+                const u32 v = p2[rbegin[k] + (p - vstart[k])];
+                word[j] = final_word(v, k);
+                lo[j] = (unsigned char)(v >> shift);
+                atomicAdd(&cnt[v >> shift], 1u);
+            }
+        }
+        __syncthreads();
+        u32 mine = tid < 128 ? cnt[tid] : 0;
+        for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
+            u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
+            __syncthreads();
+            if (tid < 128) cnt[tid] += v;
+            __syncthreads();
+        }
+        if (tid < L) {
+            const u32 start = cnt[tid] - mine; // local
+            cur[tid] = start;
+            off[((u64)q << g.b3) + tid] = out_base + start;
+        }
+        if (q == g.Q - 1 && tid == 0) off[NB] = out_base + N;
+        __syncthreads();
+#pragma unroll
+        for (unsigned j = 0; j < K3_PER; j++) {
+            const u32 p = tid + j * K3_THREADS;
+            if (p < N) outbuf[atomicAdd(&cur[lo[j]], 1u)] = word[j];
+        }
+        __syncthreads();
+        for (u32 p = tid; p < N; p += K3_THREADS) sorted[out_base + p] = outbuf[p];
+        return;
+    }
+
+    // oversized cell (heavily skewed scalars): count, then rank straight into global memory
+    for (u32 p = tid; p < N; p += K3_THREADS) {
+        const unsigned k = window_of(p);
+        atomicAdd(&cnt[p2[rbegin[k] + (p - vstart[k])] >> shift], 1u);
     }
     __syncthreads();
     u32 mine = tid < 128 ? cnt[tid] : 0;
-    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
+    for (unsigned d = 1; d < 128; d <<= 1) {
         u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
         __syncthreads();
         if (tid < 128) cnt[tid] += v;
@@ -590,47 +687,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k3_merge(const u32 *__restrict__
     }
     if (q == g.Q - 1 && tid == 0) off[NB] = out_base + N;
     __syncthreads();
-    const u32 id_mask = (1u << g.log_n) - 1;
-    for (u32 cbeg = 0; cbeg < N; cbeg += BS_CHUNK) { // N is uniform over the block: barriers are safe
-        const u32 cend = min(cbeg + BS_CHUNK, N);
-        if (tid < 128) {
-            lstart[tid] = 0;
-            lcur[tid] = 0;
-        }
-        __syncthreads();
-        for (u32 p = cbeg + tid; p < cend; p += SORT_THREADS) {
-            unsigned k;
-            atomicAdd(&lstart[fetch(p, k) >> shift], 1u);
-        }
-        __syncthreads();
-        u32 c0 = tid < 128 ? lstart[tid] : 0;
-        for (unsigned d = 1; d < 128; d <<= 1) {
-            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
-            __syncthreads();
-            if (tid < 128) lstart[tid] += v;
-            __syncthreads();
-        }
-        if (tid < 128) {
-            lstart[tid] -= c0; // exclusive
-            cnt[tid] = c0;
-        }
-        __syncthreads();
-        for (u32 p = cbeg + tid; p < cend; p += SORT_THREADS) {
-            unsigned k;
-            u32 v = fetch(p, k);
-            u32 l = v >> shift;
-            u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
-            words[slot] = (v & id_mask) | (k << g.log_n) | (((v >> g.log_n) & 1u) << 31); // row k*n + i of the tables
-            lo_of[slot] = (unsigned char)l;
-        }
-        __syncthreads();
-        for (u32 j = tid; j < cend - cbeg; j += SORT_THREADS) {
-            u32 l = lo_of[j];
-            sorted[cur[l] + (j - lstart[l])] = words[j];
-        }
-        __syncthreads();
-        if (tid < 128) cur[tid] += cnt[tid];
-        __syncthreads();
+    for (u32 p = tid; p < N; p += K3_THREADS) {
+        const unsigned k = window_of(p);
+        const u32 v = p2[rbegin[k] + (p - vstart[k])];
+        sorted[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
     }
 }
 
@@ -716,7 +776,7 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
     const SortGeom g = plain_geom(log_n, c);
-    return align256(n * W * 2) + align256((size_t)W * g.tiles * g.H * 4) + 2 * align256((size_t)W * (g.H + 1) * 4) + align256((size_t)W * (NB + 1) * 4) +
+    return align256(n * W * 2) + 2 * align256((size_t)W * g.tiles * g.H * 4) + 2 * align256((size_t)W * (g.H + 1) * 4) + align256((size_t)W * (NB + 1) * 4) +
            2 * align256(n * W * 4) + 4096;
 }
 
@@ -730,12 +790,13 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
     uint16_t *d_dig = (uint16_t *)arena.take(n * W * 2);
     u32 *d_thist = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
+    u32 *d_tpref = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (geom.H + 1) * 4);
     u32 *d_ptot = (u32 *)arena.take((size_t)W * (geom.H + 1) * 4);
     u32 *d_p1 = (u32 *)arena.take(n * W * 4);
     u32 *d_off = (u32 *)arena.take((size_t)W * (NB + 1) * 4);
     u32 *d_sorted = (u32 *)arena.take(n * W * 4);
-    if (!d_dig || !d_thist || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
+    if (!d_dig || !d_thist || !d_tpref || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
 
     if (fr == 0)
         launch_digits<Bn254Fr, uint16_t>(stream, scalars, d_dig, n, plan);
@@ -743,11 +804,15 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
         launch_digits<Bls377Fr, uint16_t>(stream, scalars, d_dig, n, plan);
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
-    hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_ptot, geom);
+    hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_tpref, d_ptot, geom);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, geom);
-    hipLaunchKernelGGL((k_part_scatter<uint16_t, u32>), dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_poff, d_p1, geom);
+    hipLaunchKernelGGL((k_part_scatter<uint16_t, u32>), dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_tpref, d_poff, d_p1, geom);
     if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
-    hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
+    static const bool direct = getenv("PANDA_SORT_DIRECT") != nullptr; // experiment switch
+    if (direct)
+        hipLaunchKernelGGL(k_bucket_sort_direct, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
+    else
+        hipLaunchKernelGGL(k_bucket_sort, dim3(geom.H, W), dim3(SORT_THREADS), 0, stream, d_p1, d_poff, d_off, d_sorted, geom, NB);
     out->off = d_off;
     out->sorted = d_sorted;
     out->lists = W;
@@ -773,9 +838,9 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
     const unsigned NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
-    return align256(E * 4) + align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 8) +
-           align256((size_t)(g.S + 1) * 4) + align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
-           align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + align256((size_t)g.Q * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
+    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 8) +
+           align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
+           align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
            align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
 }
 
@@ -797,19 +862,22 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
 
     u32 *d_dig = (u32 *)arena.take(E * 4);
     u32 *d_thist1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
+    u32 *d_tpref1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     u32 *d_ptot = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     void *d_p1 = arena.take(E * (wide ? 8 : 4));
     u32 *d_segtile = (u32 *)arena.take((size_t)(g.S + 1) * 4);
     u32 *d_thist2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
+    u32 *d_tpref2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
     u32 *d_tot2 = (u32 *)arena.take((size_t)g.S * g.H2 * 4);
     u32 *d_suboff = (u32 *)arena.take((size_t)g.S * (g.H2 + 1) * 4);
     u32 *d_p2 = (u32 *)arena.take(E * 4);
     u32 *d_cellcnt = (u32 *)arena.take((size_t)g.Q * 4);
     u32 *d_blksum = (u32 *)arena.take((size_t)qblocks * 4);
+    u32 *d_celloff = (u32 *)arena.take((size_t)(g.Q + 1) * 4);
     u32 *d_off = (u32 *)arena.take((size_t)(NB + 1) * 4);
     u32 *d_sorted = (u32 *)arena.take(E * 4);
-    if (!d_dig || !d_thist1 || !d_poff || !d_ptot || !d_p1 || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum ||
+    if (!d_dig || !d_thist1 || !d_tpref1 || !d_tpref2 || !d_poff || !d_ptot || !d_p1 || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum || !d_celloff ||
         !d_off || !d_sorted)
         return hipErrorOutOfMemory;
 
@@ -820,28 +888,29 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     // level 1, per window
     hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);
-    hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_ptot, g1);
+    hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_tpref1, d_ptot, g1);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, g1);
     if (wide)
-        hipLaunchKernelGGL((k_part_scatter<u32, u64>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_poff, (u64 *)d_p1, g1);
+        hipLaunchKernelGGL((k_part_scatter<u32, u64>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, (u64 *)d_p1, g1);
     else
-        hipLaunchKernelGGL((k_part_scatter<u32, u32>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_poff, (u32 *)d_p1, g1);
+        hipLaunchKernelGGL((k_part_scatter<u32, u32>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, (u32 *)d_p1, g1);
     // level 2, per level-1 partition
     hipLaunchKernelGGL(k2_seg_tiles, dim3(1), dim3(SORT_THREADS), 0, stream, d_poff, d_segtile, g);
     if (wide)
         hipLaunchKernelGGL(k2_hist<u64>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, g);
     else
         hipLaunchKernelGGL(k2_hist<u32>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, g);
-    hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, g.S), dim3(1024), 0, stream, d_thist2, d_segtile, d_tot2, g);
+    hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, g.S), dim3(1024), 0, stream, d_thist2, d_tpref2, d_segtile, d_tot2, g);
     hipLaunchKernelGGL(k2_offsets, dim3(g.S), dim3(256), 0, stream, d_tot2, d_suboff, g);
     if (wide)
-        hipLaunchKernelGGL(k2_scatter<u64>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, d_suboff, d_p2, g);
+        hipLaunchKernelGGL(k2_scatter<u64>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
     else
-        hipLaunchKernelGGL(k2_scatter<u32>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, d_suboff, d_p2, g);
+        hipLaunchKernelGGL(k2_scatter<u32>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
     if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
     // level 3, per cell
-    hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_poff, d_suboff, d_cellcnt, d_blksum, g);
-    hipLaunchKernelGGL(k3_merge, dim3(g.Q), dim3(SORT_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_cellcnt, d_blksum, d_off, d_sorted, g, NB);
+    hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_suboff, d_cellcnt, d_blksum, g);
+    hipLaunchKernelGGL(k3_cell_offsets, dim3(qblocks), dim3(1024), 0, stream, d_cellcnt, d_blksum, d_celloff, g);
+    hipLaunchKernelGGL(k3_merge, dim3(g.Q), dim3(K3_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB);
     out->off = d_off;
     out->sorted = d_sorted;
     out->lists = 1;

@@ -99,6 +99,7 @@ int main()
         gm.scalars_len.push_back(scalars.size());
         const size_t bi = gm.d_bases.size() - 1, si = gm.d_scalars.size() - 1;
         if (k == 14) REQUIRE(gm.register_cached_bases(bi, k) == PandaGpuError::Ok); // conversion cached from here on
+        if (k == 12) REQUIRE(gm.precompute_cached_bases(bi, k) == PandaGpuError::Ok); // window tables: same group element
         std::vector<uint8_t> r1, r2, r3, r4;
         REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, bi, &r1) == PandaGpuError::Ok);
         REQUIRE(panda_msm_bn254_gpu_with_cached_scalars(gm, si, Bytes{bases.data(), bases.size()}, &r2) == PandaGpuError::Ok);

@@ -645,3 +645,16 @@ def test_msm_precomputed_tables_baseline_sizes(gm, cid, k):
     out, scalars, tables, bits = _msm_precomputed_on_device(gm, cid, k, 0, seed_b, 0x5CA1A8 + k)
     assert tables >= 2
     assert (po.to_affine(cid, out) == po.expected_from_linearity(cid, seed_b, scalars)).all()
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "ones", "half_zero"])
+def test_msm_precomputed_tables_skewed_2_15(gm, kind):
+    """2^15 equal scalars put a whole window into one bucket: level-2 segments of many tiles, level-3 cells beyond the
+    register-resident size, buckets cut into hundreds of chunk pieces."""
+    n = 1 << 15
+    bases = po.gen_bases(0, 56, n)
+    idx = gm.add_cached_bases(bases)
+    gm.precompute_cached_bases(idx, curve=0, window_bits=16)
+    scalars = _edge_scalars(kind, n)
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.expected_from_linearity(0, 56, scalars)).all()
