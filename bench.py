@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-register", action="store_true", help="do not register the cached bases (plain drop-in call path)")
     ap.add_argument("--no-tables", action="store_true", help="register the cached bases without precomputed window tables")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra without-tables measurement (profiling runs)")
     return ap.parse_args()
 
 
@@ -202,7 +203,7 @@ def main():
         }
         if world == 1:
             out["pcie_inclusive"] = pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n)
-            if not args.no_register and not args.no_tables:
+            if not args.no_register and not args.no_tables and not args.no_compare:
                 out["without_tables"] = without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, max(2, args.steps // 2))
         if not args.no_ntt:
             out["ntt"] = ntt_figure(lib, ffi, torch, dev, pstream)

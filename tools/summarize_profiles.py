@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def latest(pattern):
-    files = sorted(glob.glob(os.path.join(ROOT, pattern)), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, pattern), recursive=True), key=os.path.getmtime)
     return files[-1]
 
 
@@ -25,22 +25,22 @@ def short(k):
 
 def main():
     tag = sys.argv[1]
-    shutil.copy(latest("gpurun_out/prof_stats/*/*_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(latest("gpurun_out/prof_stats/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
     res = {}
     for name in ("fetch", "write"):
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(latest(f"gpurun_out/prof_{name}/*/*_counter_collection.csv"))):
+        for r in csv.DictReader(open(latest(f"gpurun_out/prof_{name}/**/*counter_collection.csv"))):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         res[name] = agg
     rows = []
     for k in sorted(res["fetch"]):
-        if not k.startswith("k_"):
+        if not re.match(r"k\d?_", k):
             continue
         fv, wv = res["fetch"][k], res["write"].get(k, [0])
         f, w = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
         rows.append((k, len(fv), f, 2 * f, w, 2 * f + w))
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_bytes.csv"), "w") as o:
-        o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt (BN254 MSM 2^24)\n")
+        o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt --no-compare (BN254 MSM 2^24, precomputed tables)\n")
         o.write("# bytes per launch = counter (KB) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane reads);\n")
         o.write("# k_convert_bases calibrates the correction: it reads 2^24 * 64 B = 1.074 GB\n")
         o.write("kernel,launches,fetch_size_raw_bytes,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
