@@ -1,40 +1,13 @@
-// msm.hip -- Pippenger multi-scalar multiplication for gfx950.
-//
-// Drop-in for the reference's GPU path behind panda_msm_execute_bn254
-// (src/cuda/core/unit/msm/msm_cuda.cuh:551-784), redesigned rather than translated:
-//
-//   reference (msm_cuda.cuh)                           here
-//   ------------------------------------------------   -----------------------------------------------
-//   scalars de-Montgomeryed IN PLACE (:148-157)        digits kernel reads scalars, never writes them
-//   unsigned c-bit digits, 2^c - 1 buckets/window      signed digits, 2^(c-1) buckets/window (base negation is free)
-//   one thread per bucket walks its list (:373-409)    flat chunks of K sorted entries per thread: every thread does
-//     -> collapses on skewed scalars                     exactly K mixed adds whatever the bucket sizes; bucket pieces
-//                                                        cut by a chunk boundary are merged by a fix-up kernel
-//   each bucket weighted by c doublings + adds         segmented running sums (2 adds per bucket) + one short
-//     (:411-420, ~240 mulmods per bucket)                double-and-add per 4 buckets + tree reduction
-//   Jacobian madd 7M+4S on 8x32-bit PTX carry chains   XYZZ madd 8M+2S on 9x29-bit limbs / v_mad_u64_u32 (fe29.h)
-//   9 cudaDeviceSynchronize per call (:611-755)        one stream, one synchronisation before the host Horner
-//   scratch cudaMallocAsync'd and freed per call       per-thread arena kept between calls
-//
-// Pipeline (all on cfg.stream):
-//   k_convert_bases   wire affine -> internal Montgomery radix, 64 B/point (96 B BLS12-377)
-//   k_digits          scalar -> canonical -> W signed c-bit digits (u16 codes, window-major)
-//   k_part_hist/scan/scatter  level 1 of the sort: (id, sign, lo bits) words into 2^hi partitions, LDS histograms and cursors
-//   k_bucket_sort     level 2: one workgroup per partition ranks the lo bits in LDS -> bucket offsets + point-id lists
-//   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
-//   k_fixup           merge bucket pieces that straddle chunks
-//   k_reduce_groups   running sums over groups of buckets
-//   k_bit_sums/finish weighted sum of the group sums, bit by bit -> one point per window
-//   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743), output conversion
+// msm.hip -- curve-independent host side of the MSM: scratch arena, cached-bases registry, window policies, C ABI.
+// The kernels and the per-call driver live in msm_impl.h (instantiated per curve in msm_bn254.hip / msm_bls377.hip),
+// the digit extraction and the bucket sort in msm_sort.hip.
 #include <algorithm>
 #include <mutex>
 #include <vector>
 
-#include "curve29.h"
-#include "msm_sort.h"
-#include "panda_internal.h"
+#include "msm_impl.h"
 
-using namespace panda29;
+typedef uint64_t u64;
 
 namespace panda {
 
@@ -91,475 +64,13 @@ hipError_t release_thread_arena() { return thread_arena().release(); }
 
 namespace {
 
-
-struct CurveBn254 {
-    typedef Bn254Fq Fq;
-    typedef Bn254Fr Fr;
-};
-struct CurveBls377 {
-    typedef Bls377Fq Fq;
-    typedef Bls377Fr Fr;
-};
-
-// ------------------------------------------------------------------------------- HBM layouts
-// XYZZ point: 4*N u32, array of structs (144 B for N = 9, 224 B for N = 14; both multiples of 16).
-template <class F>
-__device__ __forceinline__ void store_xyzz(u32 *dst, const Xyzz<F> &p)
-{
-    constexpr int N = F::N;
-    u32 tmp[4 * N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        tmp[i] = p.X.l[i];
-        tmp[N + i] = p.Y.l[i];
-        tmp[2 * N + i] = p.ZZ.l[i];
-        tmp[3 * N + i] = p.ZZZ.l[i];
-    }
-    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-#pragma unroll
-    for (int i = 0; i < N; i++) d4[i] = make_uint4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
-}
-
-template <class F>
-__device__ __forceinline__ void load_xyzz(Xyzz<F> &p, const u32 *src)
-{
-    constexpr int N = F::N;
-    u32 tmp[4 * N];
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint4 v = s4[i];
-        tmp[4 * i] = v.x;
-        tmp[4 * i + 1] = v.y;
-        tmp[4 * i + 2] = v.z;
-        tmp[4 * i + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        p.X.l[i] = tmp[i];
-        p.Y.l[i] = tmp[N + i];
-        p.ZZ.l[i] = tmp[2 * N + i];
-        p.ZZZ.l[i] = tmp[3 * N + i];
-    }
-}
-
-template <int WORDS>
-__device__ __forceinline__ void load_words(u32 *dst, const u32 *src)
-{
-    static_assert(WORDS % 4 == 0, "vector loads");
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-#pragma unroll
-    for (int i = 0; i < WORDS / 4; i++) {
-        uint4 v = s4[i];
-        dst[4 * i] = v.x;
-        dst[4 * i + 1] = v.y;
-        dst[4 * i + 2] = v.z;
-        dst[4 * i + 3] = v.w;
-    }
-}
-
-template <int WORDS>
-__device__ __forceinline__ void store_words(u32 *dst, const u32 *src)
-{
-    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-#pragma unroll
-    for (int i = 0; i < WORDS / 4; i++) d4[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-}
-
-// ------------------------------------------------------------------------------- kernels
-
-// wire affine (Montgomery radix 2^(32L)) -> internal radix 2^(29N), canonical, packed in 2*L words.
-// A wire identity (x == 0, affine.cuh:72-75) becomes all zeros.
-template <class F>
-__global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ wire, u32 *__restrict__ out, u64 n)
-{
-    constexpr int L = F::L;
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[2 * L], o[2 * L];
-    load_words<2 * L>(w, wire + i * 2 * L);
-    Fe<F> x, y;
-    bool inf = affine_from_wire(x, y, w);
-    fe_reduce_once(x);
-    fe_reduce_once(y);
-    fe_pack(o, x);
-    fe_pack(o + L, y);
-    if (inf) {
-#pragma unroll
-        for (int k = 0; k < 2 * L; k++) o[k] = 0;
-    }
-    store_words<2 * L>(out + i * 2 * L, o);
-}
-
-// first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
-__device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
-{
-    u32 lo = 0, hi = NB; // invariant: off[lo] <= pos < off[hi]
-    while (hi - lo > 1) {
-        u32 mid = (lo + hi) >> 1;
-        if (off[mid] <= pos) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// a converted base as it sits in HBM: 2*L words, all zero for the identity
-template <class F>
-struct PackedBase {
-    u32 w[2 * F::L];
-};
-
-template <class F>
-__device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
-{
-    load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
-}
-
-template <class F>
-__device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const PackedBase<F> &b, u32 entry)
-{
-    constexpr int L = F::L;
-    u32 nz = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * L; k++) nz |= b.w[k];
-    inf = (nz == 0);
-    fe_unpack(x, b.w);
-    fe_unpack(y, b.w + L);
-    if (entry >> 31) {
-        Fe<F> ny;
-        fe_neg<F, 1>(ny, y); // y is canonical (< p)
-        y = ny;
-    }
-}
-
-// The hot kernel.  Thread t of window w owns sorted entries [t*K, t*K + K) of that window and adds the
-// bases they name into the accumulators of the buckets they fall in; the first and last bucket of a
-// chunk may continue in the neighbouring chunks, those pieces go to `parts` and are merged by k_fixup.
-// Replaces aggerate_buckets_groups_kernel's per-bucket list walk (msm_cuda.cuh:373-409).
-template <class F>
-__global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
-                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
-                                                    unsigned chunks)
-{
-    constexpr int PW = 4 * F::N;
-    const unsigned w = blockIdx.y;
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= chunks) return;
-    const u32 *ow = off + (u64)w * (NB + 1);
-    const u32 nw = ow[NB];
-    const u32 start = t * K;
-    if (start >= nw) return;
-    const u32 end = min(start + K, nw);
-    const u32 *sw = sorted + (u64)w * stride;
-    u32 *pw = parts + ((u64)w * chunks + t) * 2 * PW;
-    u32 *bw = bucket_acc + (u64)w * NB * PW;
-
-    u32 b = owner_bucket(ow, NB, start);
-    u32 next = ow[b + 1];
-    Xyzz<F> acc;
-    xyzz_set_identity(acc);
-
-    PackedBase<F> next_base;
-    u32 next_entry = sw[start];
-    fetch_base<F>(next_base, bases, next_entry);
-    for (u32 pos = start; pos < end; pos++) {
-        if (pos >= next) { // the run of bucket b ends here
-            const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
-            store_xyzz<F>(complete ? bw + (u64)b * PW : pw, acc);
-            xyzz_set_identity(acc);
-            do {
-                b++;
-                next = ow[b + 1];
-            } while (next <= pos);
-        }
-        Fe<F> cx, cy;
-        bool cinf;
-        const u32 entry = next_entry;
-        unpack_base<F>(cx, cy, cinf, next_base, entry);
-        if (pos + 1 < end) { // prefetch the next base (still packed: 16 registers) under this addition
-            next_entry = sw[pos + 1];
-            fetch_base<F>(next_base, bases, next_entry);
-        }
-        if (cinf) continue;
-        if (xyzz_is_identity(acc)) {
-            xyzz_from_affine(acc, cx, cy);
-            continue;
-        }
-        const int rare = xyzz_madd_core(acc, cx, cy);
-        if (rare) { // same x as the accumulator: reload the base instead of keeping it live through the common path
-            if (rare == 1) {
-                PackedBase<F> again;
-                fetch_base<F>(again, bases, entry);
-                unpack_base<F>(cx, cy, cinf, again, entry);
-                xyzz_dbl_affine(acc, cx, cy);
-            } else
-                xyzz_set_identity(acc);
-        }
-    }
-    // last run: complete only if the bucket both starts and ends inside the chunk
-    const bool starts_inside = ow[b] >= start;
-    const bool ends_inside = next <= end;
-    u32 *dst = (starts_inside && ends_inside) ? bw + (u64)b * PW : (starts_inside ? pw + PW : pw);
-    store_xyzz<F>(dst, acc);
-}
-
-// bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
-// also is t0's first run and started earlier -- impossible here since t0 = start / K), the ONLY run of every
-// chunk strictly between (slot 0) and the FIRST run of t1 (slot 0).
-// Buckets cut into more than LONG_SPAN pieces (heavily skewed scalars) are queued for k_fixup_long instead of being
-// summed by one thread.
-constexpr unsigned LONG_SPAN = 128;
-constexpr unsigned LONG_BLOCKS = 256; // workgroups per window that serve the queue
-
-template <class F>
-__global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB,
-                                               unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
-{
-    constexpr int PW = 4 * F::N;
-    const unsigned w = blockIdx.y;
-    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= NB) return;
-    const u32 *ow = off + (u64)w * (NB + 1);
-    const u32 s = ow[b], e = ow[b + 1];
-    if (s == e) return; // empty: bucket_acc was zeroed (identity)
-    const u32 t0 = s / K, t1 = (e - 1) / K;
-    if (t0 == t1) return; // lies inside one chunk: written by k_accumulate
-    if (t1 - t0 > LONG_SPAN) {
-        u32 slot = atomicAdd(&long_count[w], 1u); // a handful per window at most: (t1 - t0) > LONG_SPAN bounds it by chunks / LONG_SPAN
-        if (slot < long_cap) {
-            u32 *e3 = long_list + ((u64)w * long_cap + slot) * 3;
-            e3[0] = b;
-            e3[1] = t0;
-            e3[2] = t1;
-        }
-        return;
-    }
-    const u32 *pw = parts + (u64)w * chunks * 2 * PW;
-    Xyzz<F> acc, q;
-    load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
-    for (u32 t = t0 + 1; t <= t1; t++) {
-        load_xyzz<F>(q, pw + (u64)t * 2 * PW);
-        xyzz_add(acc, q);
-    }
-    store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
-}
-
-// one workgroup per queued bucket: 256 threads stride over its pieces, then an LDS tree
-template <class F>
-__global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB, unsigned chunks,
-                                                    const u32 *__restrict__ long_count, const u32 *__restrict__ long_list, unsigned long_cap)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned w = blockIdx.y, t = threadIdx.x;
-    const u32 count = min(long_count[w], long_cap);
-    const u32 *pw = parts + (u64)w * chunks * 2 * PW;
-    for (u32 item = blockIdx.x; item < count; item += gridDim.x) { // count is uniform over the block: barriers below are safe
-        const u32 *e3 = long_list + ((u64)w * long_cap + item) * 3;
-        const u32 b = e3[0], t0 = e3[1], t1 = e3[2];
-        Xyzz<F> acc, q;
-        xyzz_set_identity(acc);
-        for (u32 c = t0 + t; c <= t1; c += 256) {
-            load_xyzz<F>(q, pw + ((u64)c * 2 + (c == t0 ? 1 : 0)) * PW);
-            xyzz_add(acc, q);
-        }
-        store_xyzz<F>(lds + t * PW, acc);
-        __syncthreads();
-        for (unsigned s = 128; s > 0; s >>= 1) {
-            if (t < s) {
-                load_xyzz<F>(q, lds + (t + s) * PW);
-                xyzz_add(acc, q);
-                store_xyzz<F>(lds + t * PW, acc);
-            }
-            __syncthreads();
-        }
-        if (t == 0) store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
-        __syncthreads();
-    }
-}
-
-// ---- bucket reduction: sum over b of (b+1) * B_b per list ------------------------------------------------------------
-// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420 (~240 mulmods per bucket) with
-//   k_reduce_groups  thread g takes `group` buckets: running sums from the top give S_g = sum B_j and
-//                    T_g = sum (j+1) B_j (j local) -- two additions per bucket.  The list's value is
-//                    sum_g T_g + group * sum_g g * S_g.
-//   k_bit_sums       the weighted sum over g is taken bit by bit: slot 1+j adds up the S_g whose index has bit j
-//                    set, slot 0 adds up all T_g; plain tree reductions, no scalar multiplications.
-//   k_bit_finish     slot 1+j is doubled (j + log2 group) times;  k_slot_sum adds the slots up.
-template <class F>
-__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ gS, u32 *__restrict__ gT, unsigned NB,
-                                                       unsigned groups, unsigned group)
-{
-    constexpr int PW = 4 * F::N;
-    const unsigned w = blockIdx.y;
-    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
-    const u32 *bw = bucket_acc + (u64)w * NB * PW;
-    Xyzz<F> run, sum, q;
-    xyzz_set_identity(run);
-    xyzz_set_identity(sum);
-#pragma unroll 1
-    for (int j = (int)group - 1; j >= 0; j--) {
-        u32 b = g * group + j;
-        if (b < NB) {
-            load_xyzz<F>(q, bw + (u64)b * PW);
-            xyzz_add(run, q);
-        }
-        xyzz_add(sum, run);
-    }
-    store_xyzz<F>(gS + ((u64)w * groups + g) * PW, run);
-    store_xyzz<F>(gT + ((u64)w * groups + g) * PW, sum);
-}
-
-// block (blk, slot, w): partial sum of its share of the slot's operands -> out[w][slot][blk]
-template <class F>
-__global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, const u32 *__restrict__ gT, u32 *__restrict__ out, unsigned groups, unsigned slots,
-                                                  unsigned nblk)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned blk = blockIdx.x, slot = blockIdx.y, w = blockIdx.z, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    if (slot == 0) {
-        const u32 *src = gT + (u64)w * groups * PW;
-        for (unsigned g = blk * 256 + t; g < groups; g += nblk * 256) {
-            load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add(acc, q);
-        }
-    } else {
-        const unsigned j = slot - 1;
-        const u32 *src = gS + (u64)w * groups * PW;
-        const u32 low = (1u << j) - 1;
-        for (unsigned i = blk * 256 + t;; i += nblk * 256) { // i-th index with bit j set
-            const unsigned g = ((i & ~low) << 1) | (1u << j) | (i & low);
-            if (g >= groups) break; // g grows with i
-            load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add(acc, q);
-        }
-    }
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
-    }
-    if (t == 0) store_xyzz<F>(out + (((u64)w * slots + slot) * nblk + blk) * PW, acc);
-}
-
-// block (slot, w), 64 threads: tree over the slot's nblk partials, then slot 1+j is doubled (j + log2 group) times
-template <class F>
-__global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots, unsigned nblk, unsigned log_group)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
-    const unsigned slot = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    for (unsigned b = t; b < nblk; b += 64) {
-        load_xyzz<F>(q, in + (((u64)w * slots + slot) * nblk + b) * PW);
-        xyzz_add(acc, q);
-    }
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 32; s > 0; s >>= 1) {
-        if (t < s && t + s < nblk) { // partials beyond nblk are the identity
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const unsigned doublings = slot ? (slot - 1 + log_group) : 0;
-#pragma unroll 1
-        for (unsigned d = 0; d < doublings; d++) {
-            xyzz_dbl(q, acc);
-            acc = q;
-        }
-        store_xyzz<F>(out + ((u64)w * slots + slot) * PW, acc);
-    }
-}
-
-// block w, 64 threads: sum of the list's slots -> one point per list
-template <class F>
-__global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
-    const unsigned w = blockIdx.x, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    if (t < slots) load_xyzz<F>(acc, in + ((u64)w * slots + t) * PW);
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 32; s > 0; s >>= 1) {
-        if (t < s && t + s < slots) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
-    }
-    if (t == 0) store_xyzz<F>(out + (u64)w * PW, acc);
-}
-
-// Precomputed window tables for cached bases (the reference left the idea as a stub,
-// msm_host.cuh:248-265): row i of table k+1 is 2^width[k] times row i of table k, back in affine form, so that
-// digit d_k of scalar i is served by the single addition  d_k * T_k[i]  into a bucket space shared by all windows.
-template <class F>
-__global__ void __launch_bounds__(128) k_table_step(const u32 *__restrict__ prev, u32 *__restrict__ next, u64 n, unsigned steps)
-{
-    constexpr int L = F::L;
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    PackedBase<F> b;
-    load_words<2 * L>(b.w, prev + i * 2 * L);
-    Fe<F> x, y;
-    bool inf;
-    unpack_base<F>(x, y, inf, b, 0u);
-    u32 o[2 * L];
-    if (inf) {
-#pragma unroll
-        for (int k = 0; k < 2 * L; k++) o[k] = 0;
-    } else {
-        Xyzz<F> p, d;
-        xyzz_dbl_affine(p, x, y);
-#pragma unroll 1
-        for (unsigned s = 1; s < steps; s++) { // the group has odd order: a doubling never reaches the identity
-            xyzz_dbl(d, p);
-            p = d;
-        }
-        xyzz_to_affine_internal(x, y, p);
-        fe_reduce_once(x);
-        fe_reduce_once(y);
-        fe_pack(o, x);
-        fe_pack(o + L, y);
-    }
-    store_words<2 * L>(next + i * 2 * L, o);
-}
-
-// ------------------------------------------------------------------------------- host side
-
 thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 
 // Cached bases (README "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): a caller that keeps a base
 // set on the device for many MSMs may register it; the radix conversion k_convert_bases would repeat on every call is
 // then done once and kept next to it -- optionally together with the window tables above.  The caller promises not to
 // modify a registered buffer until it is unregistered.
-struct RegisteredBases {
-    const void *wire; // the caller's device pointer (the key)
-    void *converted;  // n rows (plain) or plan.W tables of n rows (tabled)
-    unsigned log_n, curve;
-    int device;
-    bool tabled;
-    panda::WindowPlan plan;
-    size_t bytes;
-};
+typedef panda::MsmRegistration RegisteredBases;
 std::mutex g_registry_mutex;
 std::vector<RegisteredBases> g_registry;
 
@@ -607,187 +118,14 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
     return best;
 }
 
-template <class F>
-void host_horner(Xyzz<F> &result, const std::vector<Xyzz<F>> &windows, const panda::WindowPlan &plan)
+hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg)
 {
-    Xyzz<F> acc, d;
-    xyzz_set_identity(acc);
-    for (int w = (int)windows.size() - 1; w >= 0; w--) {
-        for (unsigned k = 0; k < plan.width[w]; k++) {
-            xyzz_dbl(d, acc);
-            acc = d;
-        }
-        xyzz_add(acc, windows[w]);
-    }
-    result = acc;
-}
-
-unsigned floor_log2(u64 v)
-{
-    unsigned l = 0;
-    while (v >> (l + 1)) l++;
-    return l;
-}
-
-template <class C>
-hipError_t msm_execute(const panda_msm_configuration &cfg)
-{
-    typedef typename C::Fq Fq;
-    constexpr int PW = 4 * Fq::N;
-    constexpr int LQ = Fq::L;
-    constexpr unsigned curve = Fq::N == 9 ? 0u : 1u; // also selects the scalar field in msm_sort
-    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
-    const unsigned log_n = cfg.log_scalars_count;
-    if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;
-    const u64 n = (u64)1 << log_n;
-
+    if (cfg.log_scalars_count > 26 || !cfg.bases) return hipErrorInvalidValue;
     RegisteredBases reg{};
-    const bool registered = lookup_registered(reg, cfg.bases, log_n, curve);
-    const bool tabled = registered && reg.tabled;
-    const panda::WindowPlan plan = tabled ? reg.plan : panda::make_safe_window_plan(curve, pick_window_bits(log_n));
-    const unsigned W = plan.W;
-    const unsigned c = plan.width[0]; // widest window
-    const unsigned NB = 1u << (c - 1);
-    const unsigned lists = tabled ? 1u : W;         // independent bucket spaces
-    const u64 stride = tabled ? (u64)W << log_n : n; // entries per list (upper bound)
-    const unsigned lg = floor_log2(stride);
-    const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16)); // sorted entries per accumulate thread
-    const unsigned chunks = (unsigned)((stride + K - 1) / K);
-    unsigned log_group = NB >= (1u << 18) ? 3u : 2u; // log2 of the buckets per k_reduce_groups thread
-    if (g_reduce_group) log_group = floor_log2(g_reduce_group);
-    const unsigned group = 1u << log_group;
-    const unsigned groups = (NB + group - 1) / group;
-    unsigned slots = 1; // slot 0: the T_g; slot 1+j: the S_g whose index has bit j set
-    while ((1u << (slots - 1)) < groups) slots++;
-    const unsigned nblk = std::min(std::max(groups / 2048u, 1u), 64u); // blocks per slot in k_bit_sums
-    if (slots > 64) return hipErrorInvalidValue;
-
-    // ---- scratch
-    const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
-    const size_t sz_sort = tabled ? panda::msm_sort_tabled_bytes(log_n, plan) : panda::msm_sort_plain_bytes(log_n, plan);
-    const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
-    const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
-    const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
-    const size_t sz_l1 = panda::align256((size_t)lists * slots * nblk * PW * 4);
-    const size_t sz_win = panda::align256((size_t)lists * PW * 4);
-    const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
-    const unsigned long_cap = chunks / LONG_SPAN + 2;
-    const size_t sz_lcount = panda::align256((size_t)lists * 4);
-    const size_t sz_llist = panda::align256((size_t)lists * long_cap * 3 * 4);
-    panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_sort + sz_bacc + sz_parts + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + sz_lcount + sz_llist + 8192));
-    const u32 *d_bases = registered ? (const u32 *)reg.converted : (const u32 *)arena.take(sz_bases);
-    u32 *d_bacc = (u32 *)arena.take(sz_bacc);
-    u32 *d_parts = (u32 *)arena.take(sz_parts);
-    u32 *d_gsum = (u32 *)arena.take(sz_gsum);
-    u32 *d_gtsum = (u32 *)arena.take(sz_gsum);
-    u32 *d_l1 = (u32 *)arena.take(sz_l1);
-    u32 *d_win = (u32 *)arena.take(sz_win);
-    u32 *d_slots = (u32 *)arena.take(sz_slots);
-    u32 *d_lcount = (u32 *)arena.take(sz_lcount);
-    u32 *d_llist = (u32 *)arena.take(sz_llist);
-    if (!d_bases || !d_bacc || !d_parts || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots || !d_lcount || !d_llist) return hipErrorOutOfMemory;
-
-    struct PhaseEvents { // destroyed on every exit path
-        hipEvent_t ev[8] = {};
-        ~PhaseEvents()
-        {
-            for (auto &e : ev)
-                if (e) (void)hipEventDestroy(e);
-        }
-    } phase_events;
-    hipEvent_t(&ev)[8] = phase_events.ev;
-    for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
-    auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
-
-    PANDA_TRY(mark(0));
-    if (!registered)
-        hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
-    panda::SortResult sorted{};
-    const panda::SortEvents sort_events{ev[1], ev[2]};
-    if (tabled)
-        PANDA_TRY(panda::msm_sort_tabled(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
-    else
-        PANDA_TRY(panda::msm_sort_plain(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
-    if (sorted.lists != lists || sorted.NB != NB || sorted.stride != stride) return hipErrorInvalidValue;
-    PANDA_TRY(mark(3));
-    PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
-    hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, lists), dim3(128), 0, stream, d_bases, sorted.sorted, sorted.off, d_bacc, d_parts, stride,
-                       NB, K, chunks);
-    PANDA_TRY(mark(4));
-    PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
-    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, d_bacc, NB, K, chunks, d_lcount, d_llist,
-                       long_cap);
-    hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
-    PANDA_TRY(mark(5));
-    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
-    hipLaunchKernelGGL(k_bit_sums<Fq>, dim3(nblk, slots, lists), dim3(256), 0, stream, d_gsum, d_gtsum, d_l1, groups, slots, nblk);
-    hipLaunchKernelGGL(k_bit_finish<Fq>, dim3(slots, lists), dim3(64), 0, stream, d_l1, d_slots, slots, nblk, log_group);
-    hipLaunchKernelGGL(k_slot_sum<Fq>, dim3(lists), dim3(64), 0, stream, d_slots, d_win, slots);
-    PANDA_TRY(mark(6));
-    PANDA_TRY(hipGetLastError());
-
-    std::vector<u32> h_win((size_t)lists * PW);
-    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, (size_t)lists * PW * 4, hipMemcpyDeviceToHost, stream));
-    PANDA_TRY(hipStreamSynchronize(stream));
-
-    std::vector<Xyzz<Fq>> windows(lists);
-    for (unsigned w = 0; w < lists; w++) {
-        const u32 *src = h_win.data() + (size_t)w * PW;
-        for (int i = 0; i < Fq::N; i++) {
-            windows[w].X.l[i] = src[i];
-            windows[w].Y.l[i] = src[Fq::N + i];
-            windows[w].ZZ.l[i] = src[2 * Fq::N + i];
-            windows[w].ZZZ.l[i] = src[3 * Fq::N + i];
-        }
-    }
-    Xyzz<Fq> result;
-    if (tabled)
-        result = windows[0]; // the tables already carry the 2^lo[k] factors
-    else
-        host_horner(result, windows, plan);
-    u32 out[3 * LQ];
-    if (cfg.msm_result_coordinate_type == PROJECTIVE)
-        xyzz_to_homogeneous_wire(out, result);
-    else
-        xyzz_to_jacobian_wire(out, result);
-    // results may be a device pointer (unit.rs:32-47) or pinned host memory (msm_test.cu:53,125)
-    PANDA_TRY(hipMemcpyAsync(cfg.results, out, sizeof(out), hipMemcpyDefault, stream));
-    PANDA_TRY(mark(7));
-    PANDA_TRY(hipStreamSynchronize(stream));
-
-    float ms = 0;
-    for (int i = 0; i < 6; i++) {
-        (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-        g_phase_ms[i] = ms;
-    }
-    (void)hipEventElapsedTime(&ms, ev[6], ev[7]);
-    g_phase_ms[6] = ms;
-    (void)hipEventElapsedTime(&ms, ev[0], ev[6]);
-    g_phase_ms[7] = ms;
-    return hipSuccess;
-}
-
-template <class Fq>
-hipError_t build_registration(RegisteredBases &r, hipStream_t s)
-{
-    const u64 n = (u64)1 << r.log_n;
-    const size_t row = 2 * Fq::L * 4;
-    const unsigned tables = r.tabled ? r.plan.W : 1u;
-    r.bytes = (size_t)tables * n * row;
-    PANDA_TRY(hipMalloc(&r.converted, r.bytes));
-    u32 *t0 = (u32 *)r.converted;
-    hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32 *)r.wire, t0, n);
-    for (unsigned k = 1; k < tables; k++)
-        hipLaunchKernelGGL(k_table_step<Fq>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, t0 + (size_t)(k - 1) * n * 2 * Fq::L,
-                           t0 + (size_t)k * n * 2 * Fq::L, n, (unsigned)r.plan.width[k - 1]);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        (void)hipFree(r.converted);
-        r.converted = nullptr;
-    }
-    return e;
+    const bool registered = lookup_registered(reg, cfg.bases, cfg.log_scalars_count, curve);
+    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group};
+    return curve == 0 ? panda::msm_execute_bn254(cfg, registered ? &reg : nullptr, tuning, g_phase_ms)
+                      : panda::msm_execute_bls377(cfg, registered ? &reg : nullptr, tuning, g_phase_ms);
 }
 
 hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
@@ -810,7 +148,7 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
         r.plan = panda::make_safe_window_plan(curve, c);
         if (!panda::msm_sort_tabled_supported(log_n, r.plan)) return hipErrorInvalidValue;
     }
-    PANDA_TRY(curve == 0 ? build_registration<Bn254Fq>(r, s) : build_registration<Bls377Fq>(r, s));
+    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(r, s) : panda::msm_build_registration_bls377(r, s));
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     g_registry.push_back(r);
     return hipSuccess;
@@ -873,9 +211,9 @@ panda_error panda_msm_unregister_bases(const void *d_bases)
     return static_cast<panda_error>(e);
 }
 
-panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute<CurveBn254>(cfg)); }
+panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(0, cfg)); }
 
-panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute<CurveBls377>(cfg)); }
+panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(1, cfg)); }
 
 panda_error panda_msm_set_window_bits(unsigned window_bits)
 {
