@@ -238,6 +238,54 @@ PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, B
     return run_msm(gm, d_scalars, d_bases, log_2(scalars.len / FIELD_ELEMENT_LEN), true, false, result);
 }
 
+// additive: the upload of batch k+1 runs on the h2d stream while batch k executes on the exec stream
+PandaGpuError panda_msm_bn254_gpu_with_cached_bases_batched(const PandaGpuManager &gm, const std::vector<Bytes> &scalars, size_t bases_index,
+                                                            std::vector<std::vector<uint8_t>> *results)
+{
+    results->clear();
+    void *d_bases = gm.get_params_bases_ptr_mut(bases_index);
+    if (!d_bases) return PandaGpuError::BasesIndexErr;
+    if (scalars.empty()) return PandaGpuError::Ok;
+    const size_t size = scalars[0].len;
+    for (const Bytes &b : scalars)
+        if (b.len != size) return PandaGpuError::SchedulingErr;
+    struct Slot { // two of them: device scalars, pinned staging, pinned result, upload-done event
+        void *dev = nullptr, *pin = nullptr, *res = nullptr;
+        Event ev;
+        ~Slot()
+        {
+            if (dev) panda_free(dev);
+            if (pin) panda_free_host(pin);
+            if (res) panda_free_host(res);
+        }
+    } slot[2];
+    const size_t used = scalars.size() < 2 ? scalars.size() : 2;
+    for (size_t i = 0; i < used; i++) {
+        if (!slot[i].ev.ok) return PandaGpuError::EventCreateErr;
+        if (panda_malloc(&slot[i].dev, size) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        if (panda_malloc_host(&slot[i].pin, size) != 0 || panda_malloc_host(&slot[i].res, 96) != 0) return PandaGpuError::CreateContextError;
+    }
+    auto upload = [&](size_t k) -> PandaGpuError {
+        Slot &s = slot[k & 1];
+        std::memcpy(s.pin, scalars[k].data, size);
+        if (panda_memcpy_async(s.dev, s.pin, size, gm.get_h2d_stream()) != 0) return PandaGpuError::AsyncMemcopyErr;
+        return panda_event_record(s.ev.ev, gm.get_h2d_stream()) == 0 ? PandaGpuError::Ok : PandaGpuError::EventRecordErr;
+    };
+    PandaGpuError e = upload(0);
+    for (size_t k = 0; e == PandaGpuError::Ok && k < scalars.size(); k++) {
+        Slot &s = slot[k & 1];
+        if (panda_stream_wait_event(gm.get_exec_stream(), s.ev.ev) != 0) e = PandaGpuError::StreamWaitEventErr;
+        if (e == PandaGpuError::Ok && k + 1 < scalars.size()) e = upload(k + 1);
+        if (e != PandaGpuError::Ok) break;
+        panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_bases, s.dev, s.res, log_2(size / FIELD_ELEMENT_LEN),
+                                    gm.get_msm_result_coordinate_type()};
+        if (panda_msm_execute_bn254(cfg) != 0) e = PandaGpuError::SchedulingErr;
+        if (e == PandaGpuError::Ok) results->emplace_back((const uint8_t *)s.res, (const uint8_t *)s.res + 96);
+    }
+    panda_stream_sync(gm.get_h2d_stream()); // nothing of ours may still be in flight when the slots are freed
+    return e;
+}
+
 PandaGpuError panda_msm_bn254_gpu_with_cached_scalars(const PandaGpuManager &gm, size_t scalars_index, Bytes bases, std::vector<uint8_t> *result)
 {
     void *d_scalars = gm.get_params_scalars_ptr_mut(scalars_index);

@@ -124,6 +124,9 @@ PandaGpuError memory_alloc_and_copy(const PandaGpuManager &gm, Bytes h_values, p
 // gpu_manager/unit.rs -- results are 96 bytes X||Y||Z (Montgomery limbs)
 PandaGpuError panda_msm_bn254_gpu(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result);                    // :10-101
 PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, Bytes scalars, size_t bases_index, std::vector<uint8_t> *result);   // :103-188
+// additive: a run of MSMs over one cached base set, scalar uploads overlapped with execution (h2d / exec streams + events)
+PandaGpuError panda_msm_bn254_gpu_with_cached_bases_batched(const PandaGpuManager &gm, const std::vector<Bytes> &scalars, size_t bases_index,
+                                                            std::vector<std::vector<uint8_t>> *results);
 PandaGpuError panda_msm_bn254_gpu_with_cached_scalars(const PandaGpuManager &gm, size_t scalars_index, Bytes bases, std::vector<uint8_t> *result); // :190-275
 PandaGpuError panda_msm_bn254_gpu_with_cached_input(const PandaGpuManager &gm, size_t scalars_index, size_t bases_index, std::vector<uint8_t> *result); // :277-361
 PandaGpuError panda_msm_bn254_gpu_host(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result);               // :363-416

@@ -110,6 +110,13 @@ int main()
         const std::vector<uint8_t> want = affine_of(gpu, false);
         REQUIRE(affine_of(r1, false) == want && affine_of(r2, false) == want && affine_of(r3, false) == want && affine_of(r4, true) == want);
         REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, 99, &r1) == PandaGpuError::BasesIndexErr);
+        if (k == 12) { // batched pipeline over the cached (tabled) bases: same point as the single call, for every batch
+            std::vector<std::vector<uint8_t>> many;
+            const std::vector<Bytes> batches(3, Bytes{scalars.data(), scalars.size()});
+            REQUIRE(panda_msm_bn254_gpu_with_cached_bases_batched(gm, batches, bi, &many) == PandaGpuError::Ok);
+            REQUIRE(many.size() == 3);
+            for (const auto &m : many) REQUIRE(affine_of(m, false) == want); // same point; the Jacobian representative depends on the addition order
+        }
         printf("Run k = %u, compare successfully\n", k);
     }
 

@@ -282,6 +282,63 @@ def panda_msm_bn254_gpu_with_cached_bases(gm: PandaGpuManager, scalars, bases_in
     return _msm_device(gm, d_scalars, d_bases, log_2(s.size // FIELD_ELEMENT_LEN), curve, True, False)
 
 
+def panda_msm_bn254_gpu_with_cached_bases_batched(gm: PandaGpuManager, scalars_batches, bases_index: int, curve: int = BN254) -> list:
+    """Additive: a run of MSMs over one cached base set, using the manager's three streams the way
+    wrapper.rs:12-14 intends them: the scalars of batch k+1 cross PCIe on the h2d stream while batch k executes on the
+    exec stream; an event orders each execute after its own upload.  Two device buffers and one pinned staging buffer
+    per slot, allocated once.  Returns the results in order; each equals panda_msm_bn254_gpu_with_cached_bases."""
+    batches = [_as_bytes(b) for b in scalars_batches]
+    if not batches:
+        return []
+    d_bases = gm.get_params_bases_ptr_mut(bases_index)
+    if d_bases is None:
+        raise PandaGpuError("BasesIndexErr")
+    size = batches[0].size
+    if any(b.size != size for b in batches):
+        raise PandaGpuError("SchedulingErr")
+    log_n = log_2(size // FIELD_ELEMENT_LEN)
+    lib = ffi.load()
+    nres = _RESULT_BYTES[curve]
+    fn = lib.panda_msm_execute_bn254 if curve == BN254 else lib.panda_msm_execute_bls12_377
+    slots, results = [], []
+    try:
+        for _ in range(min(2, len(batches))):
+            dev, pin, res = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            ffi.check(lib.panda_malloc(C.byref(dev), size), "AsyncPoolMallocErr")
+            slots.append([dev, pin, res, PandaEventHandle()])
+            ffi.check(lib.panda_malloc_host(C.byref(pin), size), "CreateContextError")
+            slots[-1][1] = pin
+            ffi.check(lib.panda_malloc_host(C.byref(res), nres), "CreateContextError")
+            slots[-1][2] = res
+
+        def upload(k):
+            dev, pin, _, ev = slots[k & 1]
+            C.memmove(pin, _ptr(batches[k]), size)  # pageable -> pinned, on the host while the GPU works
+            ffi.check(lib.panda_memcpy_async(dev, pin, size, gm.h2d_stream.raw), "AsyncMemcopyErr")
+            ev.record(gm.h2d_stream)
+
+        upload(0)
+        for k in range(len(batches)):
+            dev, _, res, ev = slots[k & 1]
+            ffi.check(lib.panda_stream_wait_event(gm.exec_stream.raw, ev.raw), "StreamWaitEventErr")
+            if k + 1 < len(batches):
+                upload(k + 1)  # the other slot: its previous execute has returned, so its buffers are free
+            cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d_bases, dev, res, log_n, gm.msm_result_coordinate_type)
+            ffi.check(fn(cfg), "SchedulingErr")  # synchronous: the result is in `res` on return
+            results.append(np.frombuffer((C.c_uint8 * nres).from_address(res.value), dtype=np.uint8).copy())
+    finally:
+        gm.h2d_stream.sync()
+        for dev, pin, res, ev in slots:
+            ev.destroy()
+            if dev:
+                lib.panda_free(dev)
+            if pin:
+                lib.panda_free_host(pin)
+            if res:
+                lib.panda_free_host(res)
+    return results
+
+
 def panda_msm_bn254_gpu_with_cached_scalars(gm: PandaGpuManager, scalars_index: int, bases, curve: int = BN254) -> np.ndarray:
     """unit.rs:190-275: n comes from the bases length (len / 64, unit.rs:203)."""
     b = _as_bytes(bases)

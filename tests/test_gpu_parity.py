@@ -658,3 +658,24 @@ def test_msm_precomputed_tables_skewed_2_15(gm, kind):
     scalars = _edge_scalars(kind, n)
     out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
     assert (affine_of(0, out) == po.expected_from_linearity(0, 56, scalars)).all()
+
+
+@pytest.mark.parametrize("tabled", [False, True])
+def test_msm_batched_pipeline_over_cached_bases(gm, tabled):
+    """upload of batch k+1 on the h2d stream under the execution of batch k; results in order and equal
+    to the one-at-a-time calls."""
+    n = 1 << 13
+    bases = po.gen_bases(0, 9700, n)
+    idx = gm.add_cached_bases(bases)
+    if tabled:
+        gm.precompute_cached_bases(idx, curve=0)
+    batches = [po.gen_scalars(po.F_BN254_FR, 9800 + j, n) for j in range(5)]
+    outs = pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, batches, idx)
+    assert len(outs) == 5
+    for j, out in enumerate(outs):
+        assert (affine_of(0, out) == po.expected_from_linearity(0, 9700, batches[j])).all()
+        single = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, batches[j], idx)
+        assert (affine_of(0, single) == affine_of(0, out)).all()  # the Jacobian representative depends on the addition order
+    assert pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, [], idx) == []
+    with pytest.raises(ffi.PandaGpuError):
+        pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, batches[:1], 999)
