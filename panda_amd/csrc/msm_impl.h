@@ -463,6 +463,105 @@ __global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u
     }
 }
 
+// Large bucket spaces (one list of up to 2^22 buckets): the group index is split g = hi * cols + lo, so that
+//   sum_g g S_g = cols * sum_hi hi * R_hi + sum_lo lo * C_lo,   R_hi = sum_lo S_{hi,lo},  C_lo = sum_hi S_{hi,lo}.
+// Row and column sums are plain sums (two additions per group instead of log2(groups)/2 in k_bit_sums); the two small
+// weighted sums that remain are taken bit by bit in k_bit_sums2.
+// block x < rows: row x;  rows <= x < rows + cols: column x - rows;  else: sum of the T_g of row x - rows - cols
+template <class F>
+__global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS, const u32 *__restrict__ gT, u32 *__restrict__ outR, u32 *__restrict__ outC,
+                                                     u32 *__restrict__ outT, unsigned rows, unsigned cols)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
+    const unsigned x = blockIdx.x, t = threadIdx.x;
+    Xyzz<F> acc, q;
+    xyzz_set_identity(acc);
+    u32 *dst;
+    if (x < rows) {
+        for (unsigned lo = t; lo < cols; lo += 256) {
+            load_xyzz<F>(q, gS + ((u64)x * cols + lo) * PW);
+            xyzz_add(acc, q);
+        }
+        dst = outR + (u64)x * PW;
+    } else if (x < rows + cols) {
+        const unsigned lo = x - rows;
+        for (unsigned hi = t; hi < rows; hi += 256) {
+            load_xyzz<F>(q, gS + ((u64)hi * cols + lo) * PW);
+            xyzz_add(acc, q);
+        }
+        dst = outC + (u64)lo * PW;
+    } else {
+        const unsigned hi = x - rows - cols;
+        for (unsigned lo = t; lo < cols; lo += 256) {
+            load_xyzz<F>(q, gT + ((u64)hi * cols + lo) * PW);
+            xyzz_add(acc, q);
+        }
+        dst = outT + (u64)hi * PW;
+    }
+    store_xyzz<F>(lds + t * PW, acc);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            load_xyzz<F>(q, lds + (t + s) * PW);
+            xyzz_add(acc, q);
+            store_xyzz<F>(lds + t * PW, acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz<F>(dst, acc);
+}
+
+// slot 0: sum of outT;  slot 1+j (j < a): the R_hi with bit j of hi set, doubled j + b + log_group times;
+// slot 1+a+j (j < b): the C_lo with bit j of lo set, doubled j + log_group times.  One block per slot.
+template <class F>
+__global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, const u32 *__restrict__ inC, const u32 *__restrict__ inT, u32 *__restrict__ out,
+                                                   unsigned a, unsigned b, unsigned log_group)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
+    const unsigned slot = blockIdx.x, t = threadIdx.x;
+    const unsigned rows = 1u << a, cols = 1u << b;
+    Xyzz<F> acc, q;
+    xyzz_set_identity(acc);
+    unsigned doublings = 0;
+    if (slot == 0) {
+        for (unsigned i = t; i < rows; i += 256) {
+            load_xyzz<F>(q, inT + (u64)i * PW);
+            xyzz_add(acc, q);
+        }
+    } else {
+        const bool row_slot = slot <= a;
+        const unsigned j = row_slot ? slot - 1 : slot - 1 - a;
+        const unsigned count = row_slot ? rows : cols;
+        const u32 *src = row_slot ? inR : inC;
+        doublings = j + log_group + (row_slot ? b : 0u);
+        for (unsigned i = t; i < count; i += 256)
+            if ((i >> j) & 1u) {
+                load_xyzz<F>(q, src + (u64)i * PW);
+                xyzz_add(acc, q);
+            }
+    }
+    store_xyzz<F>(lds + t * PW, acc);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            load_xyzz<F>(q, lds + (t + s) * PW);
+            xyzz_add(acc, q);
+            store_xyzz<F>(lds + t * PW, acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll 1
+        for (unsigned d = 0; d < doublings; d++) {
+            xyzz_dbl(q, acc);
+            acc = q;
+        }
+        store_xyzz<F>(out + (u64)slot * PW, acc);
+    }
+}
+
 // block w, 64 threads: sum of the list's slots -> one point per list
 template <class F>
 __global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots)
@@ -574,6 +673,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     while ((1u << (slots - 1)) < groups) slots++;
     const unsigned nblk = std::min(std::max(groups / 2048u, 1u), 64u); // blocks per slot in k_bit_sums
     if (slots > 64) return hipErrorInvalidValue;
+    // one large list: row/column decomposition of the group index (k_rowcol_sums) instead of k_bit_sums
+    const bool rowcol = lists == 1 && groups >= (1u << 14) && (groups & (groups - 1)) == 0;
+    const unsigned rc_b = rowcol ? floor_log2(groups) / 2 : 0, rc_a = rowcol ? floor_log2(groups) - rc_b : 0;
+    const unsigned rc_rows = 1u << rc_a, rc_cols = 1u << rc_b;
+    if (rowcol) slots = 1 + rc_a + rc_b;
 
     // ---- scratch
     const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
@@ -581,7 +685,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
     const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
     const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
-    const size_t sz_l1 = panda::align256((size_t)lists * slots * nblk * PW * 4);
+    const size_t sz_l1 = panda::align256(std::max((size_t)lists * slots * nblk, (size_t)2 * rc_rows + rc_cols) * PW * 4);
     const size_t sz_win = panda::align256((size_t)lists * PW * 4);
     const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
     const unsigned long_cap = chunks / LONG_SPAN + 2;
@@ -634,8 +738,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
     PANDA_TRY(mark(5));
     hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
-    hipLaunchKernelGGL(k_bit_sums<Fq>, dim3(nblk, slots, lists), dim3(256), 0, stream, d_gsum, d_gtsum, d_l1, groups, slots, nblk);
-    hipLaunchKernelGGL(k_bit_finish<Fq>, dim3(slots, lists), dim3(64), 0, stream, d_l1, d_slots, slots, nblk, log_group);
+    if (rowcol) {
+        u32 *d_rows = d_l1, *d_cols = d_l1 + (size_t)rc_rows * PW, *d_tsum = d_l1 + (size_t)(rc_rows + rc_cols) * PW;
+        hipLaunchKernelGGL(k_rowcol_sums<Fq>, dim3(2 * rc_rows + rc_cols), dim3(256), 0, stream, d_gsum, d_gtsum, d_rows, d_cols, d_tsum, rc_rows, rc_cols);
+        hipLaunchKernelGGL(k_bit_sums2<Fq>, dim3(slots), dim3(256), 0, stream, d_rows, d_cols, d_tsum, d_slots, rc_a, rc_b, log_group);
+    } else {
+        hipLaunchKernelGGL(k_bit_sums<Fq>, dim3(nblk, slots, lists), dim3(256), 0, stream, d_gsum, d_gtsum, d_l1, groups, slots, nblk);
+        hipLaunchKernelGGL(k_bit_finish<Fq>, dim3(slots, lists), dim3(64), 0, stream, d_l1, d_slots, slots, nblk, log_group);
+    }
     hipLaunchKernelGGL(k_slot_sum<Fq>, dim3(lists), dim3(64), 0, stream, d_slots, d_win, slots);
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());

@@ -94,6 +94,61 @@ __global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars,
     }
 }
 
+// k_digits and the level-1 histogram (k_part_hist) in one pass over the scalars: a block takes one tile of SORT_TILE
+// scalars and counts every window's partitions in LDS (W * H counters, dynamic shared memory), so the digit codes are
+// not read back for counting.  Used for large inputs, where the tiles alone fill the chip.
+struct DigitsHistGeom {
+    unsigned lo_bits, H, tiles;
+};
+
+template <class Fr, class Code>
+__global__ void __launch_bounds__(256) k_digits_hist(const u32 *__restrict__ scalars, Code *__restrict__ dig, u32 *__restrict__ tile_hist, u64 n,
+                                                     panda::WindowPlan plan, DigitsHistGeom g)
+{
+    typedef CodeTraits<Code> CT;
+    constexpr int L = Fr::L;
+    extern __shared__ u32 hist[]; // [W][H]
+    const unsigned tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned WH = plan.W * g.H;
+    for (unsigned i = tid; i < WH; i += 256) hist[i] = 0;
+    __syncthreads();
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    for (u64 i = begin + tid; i < end; i += 256) {
+        u32 w[L], s[L + 1];
+        load_words<L>(w, scalars + i * L);
+        fe_wire_to_canonical<Fr>(s, w);
+        s[L] = 0;
+        u32 carry = 0;
+        for (unsigned k = 0; k < plan.W; k++) {
+            const unsigned c = plan.width[k];
+            const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+            unsigned lo = plan.lo[k], m = lo >> 5, sh = lo & 31;
+            u32 raw = 0;
+            if (m < (unsigned)L) {
+                u64 v = s[m] | ((u64)s[m + 1] << 32);
+                raw = (u32)(v >> sh) & mask;
+            }
+            raw += carry;
+            u32 code;
+            if (raw >= half) {
+                u32 mag = full - raw;
+                carry = 1;
+                code = mag ? ((1u << CT::SIGN) | (mag - 1)) : CT::ZERO;
+            } else {
+                carry = 0;
+                code = raw ? (raw - 1) : CT::ZERO;
+            }
+            dig[(u64)k * n + i] = (Code)code;
+            if (code != CT::ZERO) atomicAdd(&hist[k * g.H + ((code & CT::MAG) >> g.lo_bits)], 1u);
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < WH; i += 256) {
+        const unsigned k = i / g.H, h = i - k * g.H;
+        tile_hist[((u64)k * g.tiles + tile) * g.H + h] = hist[i];
+    }
+}
+
 // ---- level 1 (both modes): per window, bucket id high bits -> partition ------------------------------------------
 // Bucket ids are split into `hi` (partition) and `lo` bits.  Level 1 moves every [lo][sign][point id] word into its
 // partition with per-tile LDS histograms and LDS cursors.  A partition's output range equals its input range, so no
@@ -733,6 +788,17 @@ void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, co
     hipLaunchKernelGGL((k_digits<Fr, Code>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)scalars, dig, n, plan);
 }
 
+// digits + level-1 histogram; returns false if the fused kernel does not apply (the caller then runs k_digits + k_part_hist)
+template <class Fr, class Code>
+bool launch_digits_hist(hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan, const SortGeom &g)
+{
+    const size_t lds = (size_t)plan.W * g.H * 4;
+    if (g.tiles < 512 || lds > 48 * 1024) return false;
+    const DigitsHistGeom dg{g.lo_bits, g.H, g.tiles};
+    hipLaunchKernelGGL((k_digits_hist<Fr, Code>), dim3(g.tiles), dim3(256), lds, stream, (const u32 *)scalars, dig, tile_hist, n, plan, dg);
+    return true;
+}
+
 } // namespace
 
 namespace panda {
@@ -798,12 +864,16 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     u32 *d_sorted = (u32 *)arena.take(n * W * 4);
     if (!d_dig || !d_thist || !d_tpref || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
 
-    if (fr == 0)
-        launch_digits<Bn254Fr, uint16_t>(stream, scalars, d_dig, n, plan);
-    else
-        launch_digits<Bls377Fr, uint16_t>(stream, scalars, d_dig, n, plan);
+    const bool fused = fr == 0 ? launch_digits_hist<Bn254Fr, uint16_t>(stream, scalars, d_dig, d_thist, n, plan, geom)
+                               : launch_digits_hist<Bls377Fr, uint16_t>(stream, scalars, d_dig, d_thist, n, plan, geom);
+    if (!fused) {
+        if (fr == 0)
+            launch_digits<Bn254Fr, uint16_t>(stream, scalars, d_dig, n, plan);
+        else
+            launch_digits<Bls377Fr, uint16_t>(stream, scalars, d_dig, n, plan);
+    }
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
-    hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
+    if (!fused) hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
     hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_tpref, d_ptot, geom);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, geom);
     hipLaunchKernelGGL((k_part_scatter<uint16_t, u32>), dim3(geom.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist, d_tpref, d_poff, d_p1, geom);
@@ -881,13 +951,17 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
         !d_off || !d_sorted)
         return hipErrorOutOfMemory;
 
-    if (fr == 0)
-        launch_digits<Bn254Fr, u32>(stream, scalars, d_dig, n, plan);
-    else
-        launch_digits<Bls377Fr, u32>(stream, scalars, d_dig, n, plan);
+    const bool fused = fr == 0 ? launch_digits_hist<Bn254Fr, u32>(stream, scalars, d_dig, d_thist1, n, plan, g1)
+                               : launch_digits_hist<Bls377Fr, u32>(stream, scalars, d_dig, d_thist1, n, plan, g1);
+    if (!fused) {
+        if (fr == 0)
+            launch_digits<Bn254Fr, u32>(stream, scalars, d_dig, n, plan);
+        else
+            launch_digits<Bls377Fr, u32>(stream, scalars, d_dig, n, plan);
+    }
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     // level 1, per window
-    hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);
+    if (!fused) hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);
     hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_tpref1, d_ptot, g1);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, g1);
     if (wide)
