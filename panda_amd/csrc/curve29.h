@@ -78,7 +78,10 @@ PANDA_HD void xyzz_finish(Fe<F> &X3, Fe<F> &Y3, const Fe<F> &R, const Fe<F> &Q, 
     fe_sqr(rr, R);            // R^2     < 2p
     fe_sub<F, 6>(X3, rr, t);  // X3      < (2 + 6+M) p = XB p
     fe_sub<F, B::XB>(v, Q, X3); // Q - X3 < VB p
-    fe_neg<F, 2>(nppp, PPP);  // k p - PPP < NB p
+    if constexpr (RawOperandOk<F>::value)
+        fe_neg_raw<F, 2>(nppp, PPP); // k p - PPP < NB p, limbs < 2^31: it only feeds the product below
+    else
+        fe_neg<F, 2>(nppp, PPP);
     fe_mul_add(Y3, R, v, S1, nppp); // (R (Q - X3) - S1 PPP) / R: one reduction for both products; tight, < 2p
 }
 
@@ -146,7 +149,8 @@ PANDA_HD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &p)
     r.ZZZ = t2;
 }
 
-// acc += (bx, by) for a non-identity accumulator and base; bx, by tight < 2p.  8M + 2S.
+// acc += (bx, by) for a non-identity accumulator and base; bx tight < 2p, by tight or (RawOperandOk fields) the raw31
+// output of fe_neg_raw: it only feeds the product by * ZZZ.  8M + 2S.
 // Returns 0 when done.  When the two points share their x coordinate nothing is written and the caller finishes the
 // job: 1 = same point (double the BASE, xyzz_dbl_affine), 2 = opposite points (the sum is the identity).
 // Splitting the rare cases off keeps bx, by dead after the first two products (register pressure in k_accumulate).

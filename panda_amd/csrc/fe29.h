@@ -321,6 +321,55 @@ PANDA_HD void fe_sub(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
     fe_norm(r, t);
 }
 
+// KP[K] with the per-limb bias lowered from 2^31 to 2^30 (same value): for differences that feed a multiplication
+// without being normalised first
+template <class F, int K>
+PANDA_HD constexpr u32 fe_kp30(int i)
+{
+    return i == 0 ? F::KP[K][0] - (2u << LIMB_BITS) : (i < F::N - 1 ? F::KP[K][i] - (2u << LIMB_BITS) + 2u : F::KP[K][i] + 2u);
+}
+
+// fields whose column accumulators have room for one un-normalised operand (limbs < 2^31) in fe_mul / fe_mul_add
+template <class F>
+struct RawOperandOk {
+    static constexpr bool value = F::N <= 9;
+};
+
+// r = a - b + KEFF*p, b < KB*p, WITHOUT the carry pass: limbs < 2^31 ("raw31").  a, b tight or loose.
+// The result may only be ONE operand of a fe_mul whose other operand is tight or loose, or the last operand of
+// fe_mul_add; it must not be squared, stored, or fed to another addition.  Saves the 3N instructions of fe_norm.
+template <class F, int KB>
+PANDA_HD void fe_sub_raw(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    static_assert(RawOperandOk<F>::value, "no column headroom for a raw operand in this field");
+    constexpr int K = KB + SubMargin<F>::value;
+    static_assert(K <= 200, "subtraction constant table too small");
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+        const u32 kp = fe_kp30<F, K>(i);
+#if defined(FE29_CHECK)
+        assert((u64)a.l[i] + kp >= b.l[i] && (u64)a.l[i] + kp - b.l[i] < (1ull << 31) + (1ull << 24) && "fe_sub_raw limb range");
+#endif
+        r.l[i] = a.l[i] + kp - b.l[i];
+    }
+}
+
+// r = KEFF*p - a, a < KB*p, without the carry pass (see fe_sub_raw)
+template <class F, int KB>
+PANDA_HD void fe_neg_raw(Fe<F> &r, const Fe<F> &a)
+{
+    static_assert(RawOperandOk<F>::value, "no column headroom for a raw operand in this field");
+    constexpr int K = KB + SubMargin<F>::value;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+        const u32 kp = fe_kp30<F, K>(i);
+#if defined(FE29_CHECK)
+        assert(kp >= a.l[i] && "fe_neg_raw limb range");
+#endif
+        r.l[i] = kp - a.l[i];
+    }
+}
+
 // value bound added by fe_sub<F,KB>, in units of p
 template <class F, int KB>
 struct SubGrowth {

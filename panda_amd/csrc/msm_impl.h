@@ -193,7 +193,9 @@ __device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u
     load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
 }
 
-template <class F>
+// RAW: a negated y comes back un-normalised (limbs < 2^31) -- good enough for the one product it feeds in
+// xyzz_madd_core, three instructions per limb cheaper; callers that store or square y normalise it first
+template <class F, bool RAW = false>
 __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const PackedBase<F> &b, u32 entry)
 {
     constexpr int L = F::L;
@@ -205,7 +207,10 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
     fe_unpack(y, b.w + L);
     if (entry >> 31) {
         Fe<F> ny;
-        fe_neg<F, 1>(ny, y); // y is canonical (< p)
+        if constexpr (RAW)
+            fe_neg_raw<F, 1>(ny, y); // y is canonical (< p)
+        else
+            fe_neg<F, 1>(ny, y);
         y = ny;
     }
 }
@@ -214,6 +219,9 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 // bases they name into the accumulators of the buckets they fall in; the first and last bucket of a
 // chunk may continue in the neighbouring chunks, those pieces go to `parts` and are merged by k_fixup.
 // Replaces aggerate_buckets_groups_kernel's per-bucket list walk (msm_cuda.cuh:373-409).
+#ifndef ACC_RAW_Y
+#define ACC_RAW_Y false
+#endif
 template <class F>
 __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
@@ -237,9 +245,13 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     Xyzz<F> acc;
     xyzz_set_identity(acc);
 
+    // Software pipeline: while the addition of entry `pos` runs, the base of entry pos+1 (still packed: 16 registers)
+    // and the sorted word of entry pos+2 are in flight, so neither the gather nor the dependent address load is waited
+    // for at its point of issue.
     PackedBase<F> next_base;
-    u32 next_entry = sw[start];
-    fetch_base<F>(next_base, bases, next_entry);
+    u32 cur_entry = sw[start];
+    u32 ahead_entry = start + 1 < end ? sw[start + 1] : 0u;
+    fetch_base<F>(next_base, bases, cur_entry);
     for (u32 pos = start; pos < end; pos++) {
         if (pos >= next) { // the run of bucket b ends here
             const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
@@ -252,15 +264,18 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
         }
         Fe<F> cx, cy;
         bool cinf;
-        const u32 entry = next_entry;
-        unpack_base<F>(cx, cy, cinf, next_base, entry);
-        if (pos + 1 < end) { // prefetch the next base (still packed: 16 registers) under this addition
-            next_entry = sw[pos + 1];
-            fetch_base<F>(next_base, bases, next_entry);
+        const u32 entry = cur_entry;
+        unpack_base<F, ACC_RAW_Y && RawOperandOk<F>::value>(cx, cy, cinf, next_base, entry);
+        if (pos + 1 < end) {
+            cur_entry = ahead_entry;
+            fetch_base<F>(next_base, bases, cur_entry);
+            if (pos + 2 < end) ahead_entry = sw[pos + 2];
         }
         if (cinf) continue;
         if (xyzz_is_identity(acc)) {
-            xyzz_from_affine(acc, cx, cy);
+            Fe<F> ty;
+            fe_norm(ty, cy); // a raw negated y must not be stored
+            xyzz_from_affine(acc, cx, ty);
             continue;
         }
         const int rare = xyzz_madd_core(acc, cx, cy);

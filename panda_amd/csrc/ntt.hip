@@ -151,11 +151,15 @@ struct Rounds {
             fe_reduce_small(b);
         }
         fe_add(s, a, b);
-        fe_sub<Fr, B0>(d, a, b);
-        if (di != 0) {
-            Fe<Fr> w;
+        if (RND == DEG - 1) { // last round: every twiddle is 1
+            fe_sub<Fr, B0>(d, a, b);
+        } else {
+            // every lane multiplies (w^0 = 1 for di == 0: no lane of a wave could skip the product anyway), so the
+            // difference can go into the product un-normalised
+            Fe<Fr> w, raw;
+            fe_sub_raw<Fr, B0>(raw, a, b);
             pq.load(w, di << RND);
-            fe_mul(d, d, w);
+            fe_mul(d, raw, w);
         }
         u.store(s, blk_base + i0);
         u.store(d, blk_base + i1);
