@@ -638,7 +638,7 @@ def test_msm_precomputed_tables_wide_words_2_18(gm):
     assert (po.to_affine(0, out) == po.expected_from_linearity(0, 0x70616E6461 ^ 7, scalars)).all()
 
 
-@pytest.mark.parametrize("cid,k", [(0, 20), (0, 24), (1, 22)])
+@pytest.mark.parametrize("cid,k", [(0, 20), (0, 24), (1, 22), (0, 26)])
 def test_msm_precomputed_tables_baseline_sizes(gm, cid, k):
     """BASELINE configs 2 (BN254 2^20, cached bases) and the headline 2^24 with the built-in table policy; linearity."""
     seed_b = 0x70616E6461 ^ (8 + k)
