@@ -679,3 +679,30 @@ def test_msm_batched_pipeline_over_cached_bases(gm, tabled):
     assert pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, [], idx) == []
     with pytest.raises(ffi.PandaGpuError):
         pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, batches[:1], 999)
+
+
+def test_msm_ragged_lengths_and_bad_arguments(gm):
+    """unit.rs:31: n = 2^floor(log2(len / 32)) -- a ragged scalar slice uses its leading power-of-two prefix (and as many bases).
+    Null pointers and oversize counts come back as panda_error_invalid_value, never as a crash."""
+    bases = po.gen_bases(0, 9900, 1024)
+    scalars = po.gen_scalars(po.F_BN254_FR, 9901, 1000)  # 1000 -> n = 512
+    out = pgm.panda_msm_bn254_gpu(gm, scalars, bases)
+    assert (affine_of(0, out) == po.msm_affine(0, bases[:512], scalars[:512], window_bits=9)).all()
+    out1 = pgm.panda_msm_bn254_gpu(gm, scalars[:1], bases[:1])  # a single point: log_n = 0
+    assert (affine_of(0, out1) == po.msm_affine(0, bases[:1], scalars[:1], window_bits=4)).all()
+    lib = ffi.load()
+    d = DeviceBuffer(4096)
+    for cfg in (ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, None, d.ptr, d.ptr, 2, pgm.JACOBIAN),
+                ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d.ptr, None, d.ptr, 2, pgm.JACOBIAN),
+                ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d.ptr, d.ptr, None, 2, pgm.JACOBIAN),
+                ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d.ptr, d.ptr, d.ptr, 27, pgm.JACOBIAN)):
+        assert lib.panda_msm_execute_bn254(cfg) == 1
+        assert lib.panda_msm_execute_bls12_377(cfg) == 1
+    assert lib.panda_msm_precompute_bases(0, None, 10, 0, gm.exec_stream.raw) == 1
+    assert lib.panda_msm_precompute_bases(2, d.ptr, 10, 0, gm.exec_stream.raw) == 1
+    assert lib.panda_msm_precompute_bases(0, d.ptr, 3, 30, gm.exec_stream.raw) == 1
+    assert lib.panda_msm_register_bases(0, d.ptr, 27, gm.exec_stream.raw) == 1
+    flag = C.c_uint(0)
+    bad = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, None, d.ptr, None, 4, C.pointer(flag))
+    assert lib.panda_ntt_execute_bn254_v1(bad) == 1
+    d.free()
