@@ -147,10 +147,14 @@ panda_error panda_device_disable_peer_access(int device_id); /* binding.rs:54 */
 panda_error panda_msm_setup_bls12_377(void);
 panda_error panda_msm_execute_bls12_377(const panda_msm_configuration exec_cfg);
 panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration exec_cfg);
+/* BLS12-381 G1 (the reference names the curve, curve.cuh:12, but carries no parameters for it): bases 96 B, result 144 B, curve id 2 */
+panda_error panda_msm_setup_bls12_381(void);
+panda_error panda_msm_execute_bls12_381(const panda_msm_configuration exec_cfg);
+panda_error panda_msm_execute_bls12_381_host(const panda_msm_configuration exec_cfg);
 
 /* Cached bases (README.md "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): registering a device buffer
  * of 2^log_n affine bases lets the library keep its radix-converted copy between calls instead of re-deriving it in every
- * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377. */
+ * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377, 2 BLS12-381. */
 panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream);
 panda_error panda_msm_unregister_bases(const void *d_bases);
 /* Cached bases with precomputed window tables (the lookup-table idea the reference left as a stub, msm_host.cuh:248-265):
@@ -177,6 +181,8 @@ panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exe
 /* The same transforms over the BLS12-377 scalar field (README.md:36: "easy to encapsulate ... BLS12-377 later") */
 panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 exec_cfg);
 panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_381_v1(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1 exec_cfg);
 
 /* Multi-GPU, one process per GPU.  The exchange itself is the caller's (RCCL through
  * torch.distributed or ncclAllGather): these are the per-rank halves either side of it.
@@ -186,6 +192,7 @@ panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1
 panda_error panda_msm_combine_bn254(const void *partials /* host or device, count x 96 B Jacobian */, unsigned count,
                                     panda_msm_result_coordinate_type out_type, void *result /* host, 96 B */);
 panda_error panda_msm_combine_bls12_377(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result);
+panda_error panda_msm_combine_bls12_381(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result);
 
 typedef struct panda_ntt_slab_configuration
 {

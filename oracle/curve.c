@@ -28,6 +28,10 @@ static const u32 BLS377_GX[12] = {0xb21be9efu, 0xeab9b16eu, 0xffcd394eu, 0xd5481
 static const u32 BLS377_GY[12] = {0x559c8ea6u, 0xfd82de55u, 0x34a9591au, 0xc2fe3d36u, 0x4fb82305u, 0x6d182ad4u,
                                   0xca3e52d9u, 0xbd7fb348u, 0x30afeec4u, 0x1f674f5du, 0xc5102effu, 0x01914a69u};
 
+/* BLS12-381 G1 generator (the standard one), canonical form, little-endian limbs */
+static const u32 BLS381_GX[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu, 0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+static const u32 BLS381_GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu, 0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+
 void po_generator(int curve, u32 *aff)
 {
     const po_field *f = po_curve_fq(curve);
@@ -36,6 +40,9 @@ void po_generator(int curve, u32 *aff)
         u32 one[LCMAX] = {1}, two[LCMAX] = {2};
         po_f_to_mont(f, aff, one);
         po_f_to_mont(f, aff + lc, two);
+    } else if (curve == PO_CURVE_BLS12_381) {
+        po_f_to_mont(f, aff, BLS381_GX);
+        po_f_to_mont(f, aff + lc, BLS381_GY);
     } else {
         po_f_to_mont(f, aff, BLS377_GX);
         po_f_to_mont(f, aff + lc, BLS377_GY);
@@ -47,7 +54,7 @@ int po_is_on_curve(int curve, const u32 *aff)
     const po_field *f = po_curve_fq(curve);
     const unsigned lc = f->lc;
     u32 b[LCMAX] = {0}, bm[LCMAX], y2[LCMAX], x3[LCMAX];
-    b[0] = (curve == PO_CURVE_BN254) ? 3 : 1;
+    b[0] = (curve == PO_CURVE_BN254) ? 3 : (curve == PO_CURVE_BLS12_381 ? 4 : 1); /* y^2 = x^3 + b */
     po_f_to_mont(f, bm, b);
     po_f_sqr(f, y2, aff + lc);
     po_f_sqr(f, x3, aff);

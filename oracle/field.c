@@ -21,7 +21,7 @@
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-static po_field g_fields[4] = {
+static po_field g_fields[PO_NUM_FIELDS] = {
     /* BN254 Fq */
     {8, 254, 0, {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}, {0}, {0}},
     /* BN254 Fr */
@@ -30,6 +30,9 @@ static po_field g_fields[4] = {
     {12, 377, 0, {0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu, 0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu, 0xc63b05c0u, 0x17c510eau, 0x01ae3a46u}, {0}, {0}},
     /* BLS12-377 Fr */
     {8, 253, 0, {0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu, 0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu}, {0}, {0}},
+    /* BLS12-381 Fq, Fr: the reference only names the curve (curve.cuh:12); standard parameters, parity unpinned by the reference */
+    {12, 381, 0, {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau}, {0}, {0}},
+    {8, 255, 0, {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u}, {0}, {0}},
 };
 static int g_fields_ready = 0;
 
@@ -75,7 +78,7 @@ static void dbl_mod(const po_field *f, u32 *r, const u32 *a)
 static void fields_init(void)
 {
     if (g_fields_ready) return;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PO_NUM_FIELDS; k++) {
         po_field *f = &g_fields[k];
         /* -p^-1 mod 2^32 by Newton iteration */
         u32 p0 = f->p[0], x = 1;
@@ -94,11 +97,11 @@ static void fields_init(void)
 const po_field *po_field_get(int id)
 {
     fields_init();
-    if (id < 0 || id > 3) return NULL;
+    if (id < 0 || id >= PO_NUM_FIELDS) return NULL;
     return &g_fields[id];
 }
-const po_field *po_curve_fq(int curve) { return po_field_get(curve == PO_CURVE_BN254 ? PO_FIELD_BN254_FQ : PO_FIELD_BLS12_377_FQ); }
-const po_field *po_curve_fr(int curve) { return po_field_get(curve == PO_CURVE_BN254 ? PO_FIELD_BN254_FR : PO_FIELD_BLS12_377_FR); }
+const po_field *po_curve_fq(int curve) { return po_field_get(2 * curve); }     /* field ids are (Fq, Fr) pairs in curve order */
+const po_field *po_curve_fr(int curve) { return po_field_get(2 * curve + 1); }
 
 void po_f_add(const po_field *f, u32 *r, const u32 *a, const u32 *b)
 {

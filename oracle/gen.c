@@ -63,7 +63,7 @@ void po_gen_scalars(int field_id, u64 seed, u64 first, u64 n, void *out_)
 u64 po_gen_multiplier(u64 seed, u64 i) { return splitmix64(seed ^ (0x9E3779B97F4A7C15ull * (i + 1))) | 1ull; }
 
 /* fixed-base table T[j][d-1] = d * 256^j * G (affine), j < 8, d in 1..255 */
-static u32 *g_table[2] = {NULL, NULL};
+static u32 *g_table[PO_NUM_CURVES] = {NULL};
 
 static const u32 *fixed_base_table(int curve)
 {

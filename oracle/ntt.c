@@ -181,6 +181,9 @@ int po_root_of_unity(int field_id, unsigned log_n, void *omega_mont)
     } else if (field_id == PO_FIELD_BLS12_377_FR) {
         two_adicity = 47;
         gen = 22;
+    } else if (field_id == PO_FIELD_BLS12_381_FR) {
+        two_adicity = 32;
+        gen = 7;
     } else
         return 1;
     if (log_n > two_adicity) return 1;

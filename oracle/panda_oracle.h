@@ -16,6 +16,9 @@
  * 117-168) and no NTT fixture, so NTT parity is "unpinned by the reference"; the NTT here
  * follows the definition the commented-out code implements (y[k] = sum_j x[j] w^(jk)) and is
  * pinned by the O(n^2) DFT, round trips and linearity only.
+ * BLS12-381 (curve id 2): the reference names the curve (curve.cuh:12) but holds no parameters,
+ * code or fixtures for it, so it too is "parity unpinned by the reference"; the standard
+ * parameters used here are pinned by tests/pyref.py (generator on-curve, r*G = O, group law, MSM).
  *
  * Wire formats (reference src/utils.rs:1-14, field_storage.cuh:12-16, affine.cuh:11-19,
  * projective.cuh:9-20):
@@ -36,8 +39,10 @@ extern "C" {
 
 #define PO_MAX_LC 12
 
-enum { PO_CURVE_BN254 = 0, PO_CURVE_BLS12_377 = 1 };
-enum { PO_FIELD_BN254_FQ = 0, PO_FIELD_BN254_FR = 1, PO_FIELD_BLS12_377_FQ = 2, PO_FIELD_BLS12_377_FR = 3 };
+enum { PO_CURVE_BN254 = 0, PO_CURVE_BLS12_377 = 1, PO_CURVE_BLS12_381 = 2 };
+enum { PO_FIELD_BN254_FQ = 0, PO_FIELD_BN254_FR = 1, PO_FIELD_BLS12_377_FQ = 2, PO_FIELD_BLS12_377_FR = 3, PO_FIELD_BLS12_381_FQ = 4, PO_FIELD_BLS12_381_FR = 5 };
+#define PO_NUM_FIELDS 6
+#define PO_NUM_CURVES 3
 
 typedef struct po_field {
     uint32_t lc;               /* limbs */

@@ -9,6 +9,6 @@ Nothing here imports the CPU oracle under oracle/.
 from . import gpu_ffi, gpu_manager  # noqa: F401
 from .gpu_ffi import JACOBIAN, PROJECTIVE, PandaGpuError  # noqa: F401
 from .gpu_manager import (  # noqa: F401
-    BLS12_377, BN254, PandaGpuManager, panda_intt_bn254_gpu, panda_msm_bn254_gpu, panda_msm_bn254_gpu_host,
+    BLS12_377, BLS12_381, BN254, PandaGpuManager, panda_intt_bn254_gpu, panda_msm_bn254_gpu, panda_msm_bn254_gpu_host,
     panda_msm_bn254_gpu_with_cached_bases, panda_msm_bn254_gpu_with_cached_bases_batched, panda_msm_bn254_gpu_with_cached_input, panda_msm_bn254_gpu_with_cached_scalars,
     panda_ntt_bn254_gpu, panda_ntt_bn254_gpu_v1)

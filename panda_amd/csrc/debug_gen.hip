@@ -198,6 +198,15 @@ void generator_wire(u32 *out, unsigned curve)
     if (curve == 0) {
         cx[0] = 1;
         cy[0] = 2;
+    } else if (curve == 2) { // BLS12-381 G1 generator (standard; on-curve and order checked in tests/test_oracle.py)
+        static const u32 gx[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                   0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+        static const u32 gy[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                   0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+        for (int k = 0; k < L && k < 12; k++) {
+            cx[k] = gx[k];
+            cy[k] = gy[k];
+        }
     } else {
         static const u32 gx[12] = {0xb21be9efu, 0xeab9b16eu, 0xffcd394eu, 0xd5481512u, 0xbd37cb5cu, 0x188282c8u,
                                    0xaa9d41bbu, 0x85951e2cu, 0xbf87ff54u, 0xc8fc6225u, 0xfe740a67u, 0x008848deu};
@@ -243,7 +252,7 @@ extern "C" {
 
 panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream)
 {
-    if (op > 5 || field_id > 3) return panda_error_invalid_value;
+    if (op > 5 || field_id > 5) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     u32 *r = (u32 *)d_r;
@@ -252,7 +261,9 @@ panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, cons
     case 0: hipLaunchKernelGGL(k_field_op<Bn254Fq>, grid, block, 0, s, op, r, a, b, n); break;
     case 1: hipLaunchKernelGGL(k_field_op<Bn254Fr>, grid, block, 0, s, op, r, a, b, n); break;
     case 2: hipLaunchKernelGGL(k_field_op<Bls377Fq>, grid, block, 0, s, op, r, a, b, n); break;
-    default: hipLaunchKernelGGL(k_field_op<Bls377Fr>, grid, block, 0, s, op, r, a, b, n); break;
+    case 3: hipLaunchKernelGGL(k_field_op<Bls377Fr>, grid, block, 0, s, op, r, a, b, n); break;
+    case 4: hipLaunchKernelGGL(k_field_op<Bls381Fq>, grid, block, 0, s, op, r, a, b, n); break;
+    default: hipLaunchKernelGGL(k_field_op<Bls381Fr>, grid, block, 0, s, op, r, a, b, n); break;
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -261,11 +272,12 @@ panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, cons
 
 panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream)
 {
-    if (op > 2 || curve > 1) return panda_error_invalid_value;
+    if (op > 2 || curve > 2) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 127) / 128)), block(128);
     if (curve == 0) hipLaunchKernelGGL(k_curve_op<Bn254Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
-    else hipLaunchKernelGGL(k_curve_op<Bls377Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    else if (curve == 1) hipLaunchKernelGGL(k_curve_op<Bls377Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    else hipLaunchKernelGGL(k_curve_op<Bls381Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     return static_cast<panda_error>(e);
@@ -273,11 +285,12 @@ panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const v
 
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream)
 {
-    if (curve > 1) return panda_error_invalid_value;
+    if (curve > 2) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (curve == 0) hipLaunchKernelGGL(k_gen_scalars<Bn254Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
-    else hipLaunchKernelGGL(k_gen_scalars<Bls377Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
+    else if (curve == 1) hipLaunchKernelGGL(k_gen_scalars<Bls377Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
+    else hipLaunchKernelGGL(k_gen_scalars<Bls381Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     return static_cast<panda_error>(e);
@@ -285,9 +298,13 @@ panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uin
 
 panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream)
 {
-    if (curve > 1) return panda_error_invalid_value;
+    if (curve > 2) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
-    return static_cast<panda_error>(curve == 0 ? gen_bases<Bn254Fq>(curve, seed, first, n, d_out, s) : gen_bases<Bls377Fq>(curve, seed, first, n, d_out, s));
+    switch (curve) {
+    case 0: return static_cast<panda_error>(gen_bases<Bn254Fq>(curve, seed, first, n, d_out, s));
+    case 1: return static_cast<panda_error>(gen_bases<Bls377Fq>(curve, seed, first, n, d_out, s));
+    default: return static_cast<panda_error>(gen_bases<Bls381Fq>(curve, seed, first, n, d_out, s));
+    }
 }
 
 } // extern "C"

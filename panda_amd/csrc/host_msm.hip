@@ -127,6 +127,8 @@ panda_error panda_msm_execute_bn254_host(const panda_msm_configuration cfg) { re
 
 panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration cfg) { return static_cast<panda_error>(host_msm<Bls377Fq, Bls377Fr>(cfg)); }
 
+panda_error panda_msm_execute_bls12_381_host(const panda_msm_configuration cfg) { return static_cast<panda_error>(host_msm<Bls381Fq, Bls381Fr>(cfg)); }
+
 panda_error panda_msm_combine_bn254(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result)
 {
     return static_cast<panda_error>(combine<Bn254Fq>(partials, count, out_type, result));
@@ -135,6 +137,11 @@ panda_error panda_msm_combine_bn254(const void *partials, unsigned count, panda_
 panda_error panda_msm_combine_bls12_377(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result)
 {
     return static_cast<panda_error>(combine<Bls377Fq>(partials, count, out_type, result));
+}
+
+panda_error panda_msm_combine_bls12_381(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result)
+{
+    return static_cast<panda_error>(combine<Bls381Fq>(partials, count, out_type, result));
 }
 
 } // extern "C"

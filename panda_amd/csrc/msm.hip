@@ -95,7 +95,7 @@ const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort
 // window width policy (replaces get_window_bits_count, msm_cuda.cuh:21-45)
 unsigned pick_window_bits(unsigned log_n)
 {
-    if (g_window_override) return std::min(std::max(g_window_override, 2u), 16u);
+    if (g_window_override) return std::min(std::max(g_window_override, 4u), 16u);
     int c = (int)log_n - 4;
     return (unsigned)std::min(std::max(c, 4), 16);
 }
@@ -124,13 +124,17 @@ hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg)
     RegisteredBases reg{};
     const bool registered = lookup_registered(reg, cfg.bases, cfg.log_scalars_count, curve);
     const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group};
-    return curve == 0 ? panda::msm_execute_bn254(cfg, registered ? &reg : nullptr, tuning, g_phase_ms)
-                      : panda::msm_execute_bls377(cfg, registered ? &reg : nullptr, tuning, g_phase_ms);
+    const RegisteredBases *r = registered ? &reg : nullptr;
+    switch (curve) {
+    case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms);
+    case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms);
+    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms);
+    }
 }
 
 hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
 {
-    if (curve > 1 || !d_bases || log_n > 26) return hipErrorInvalidValue;
+    if (curve > 2 || !d_bases || log_n > 26) return hipErrorInvalidValue;
     RegisteredBases r{};
     if (lookup_registered(r, d_bases, log_n, curve)) {
         if (r.tabled == tabled && (!tabled || !window_bits || r.plan.width[0] == window_bits)) return hipSuccess;
@@ -148,7 +152,7 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
         r.plan = panda::make_safe_window_plan(curve, c);
         if (!panda::msm_sort_tabled_supported(log_n, r.plan)) return hipErrorInvalidValue;
     }
-    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(r, s) : panda::msm_build_registration_bls377(r, s));
+    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(r, s) : (curve == 1 ? panda::msm_build_registration_bls377(r, s) : panda::msm_build_registration_bls381(r, s)));
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     g_registry.push_back(r);
     return hipSuccess;
@@ -162,6 +166,7 @@ extern "C" {
 
 panda_error panda_msm_setup_bn254(void) { return panda_success; }
 panda_error panda_msm_setup_bls12_377(void) { return panda_success; }
+panda_error panda_msm_setup_bls12_381(void) { return panda_success; }
 
 panda_error panda_msm_tear_down(void) { return static_cast<panda_error>(panda::release_thread_arena()); }
 
@@ -214,6 +219,8 @@ panda_error panda_msm_unregister_bases(const void *d_bases)
 panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(0, cfg)); }
 
 panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(1, cfg)); }
+
+panda_error panda_msm_execute_bls12_381(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(2, cfg)); }
 
 panda_error panda_msm_set_window_bits(unsigned window_bits)
 {

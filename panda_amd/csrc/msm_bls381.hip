@@ -1,0 +1,14 @@
+// msm_bls381.hip -- the MSM kernels and driver of msm_impl.h instantiated for BLS12-381 (G1).
+#define PANDA_MSM_IMPL
+#include "msm_impl.h"
+
+namespace panda {
+
+hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms)
+{
+    return msm_execute<CurveBls381>(cfg, reg, tuning, phase_ms);
+}
+
+hipError_t msm_build_registration_bls381(MsmRegistration &r, hipStream_t s) { return build_registration<Bls381Fq>(r, s); }
+
+} // namespace panda

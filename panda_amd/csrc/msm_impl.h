@@ -54,11 +54,13 @@ struct MsmTuning {
     unsigned reduce_group; // 0 = built-in
 };
 
-// per-curve entry points (defined in msm_bn254.hip / msm_bls377.hip)
+// per-curve entry points (defined in msm_bn254.hip / msm_bls377.hip / msm_bls381.hip)
 hipError_t msm_execute_bn254(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
 hipError_t msm_execute_bls377(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
 hipError_t msm_build_registration_bn254(MsmRegistration &r, hipStream_t s);
 hipError_t msm_build_registration_bls377(MsmRegistration &r, hipStream_t s);
+hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
+hipError_t msm_build_registration_bls381(MsmRegistration &r, hipStream_t s);
 
 } // namespace panda
 
@@ -73,10 +75,17 @@ namespace {
 struct CurveBn254 {
     typedef Bn254Fq Fq;
     typedef Bn254Fr Fr;
+    static constexpr unsigned ID = 0; // curve id of the C ABI; also selects the scalar field in msm_sort
 };
 struct CurveBls377 {
     typedef Bls377Fq Fq;
     typedef Bls377Fr Fr;
+    static constexpr unsigned ID = 1;
+};
+struct CurveBls381 {
+    typedef Bls381Fq Fq;
+    typedef Bls381Fr Fr;
+    static constexpr unsigned ID = 2;
 };
 
 // ------------------------------------------------------------------------------- HBM layouts
@@ -663,7 +672,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     typedef typename C::Fq Fq;
     constexpr int PW = 4 * Fq::N;
     constexpr int LQ = Fq::L;
-    constexpr unsigned curve = Fq::N == 9 ? 0u : 1u; // also selects the scalar field in msm_sort
+    constexpr unsigned curve = C::ID;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     const unsigned log_n = cfg.log_scalars_count;
     if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;

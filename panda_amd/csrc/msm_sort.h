@@ -7,10 +7,11 @@
 namespace panda {
 
 // BITS+1 scalar bits (one spare for the signed-digit carry) cut into W windows whose widths differ by at most one.
+constexpr unsigned MAX_WINDOWS = 72; // 4-bit windows over 256 + 8 scalar bits at most
 struct WindowPlan {
     unsigned W;
-    unsigned char width[64];
-    unsigned short lo[64];
+    unsigned char width[MAX_WINDOWS];
+    unsigned short lo[MAX_WINDOWS];
 };
 
 WindowPlan make_window_plan(unsigned total_bits, unsigned c);

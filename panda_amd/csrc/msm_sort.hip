@@ -788,6 +788,16 @@ void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, co
     hipLaunchKernelGGL((k_digits<Fr, Code>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)scalars, dig, n, plan);
 }
 
+template <class Code>
+void launch_digits_for(unsigned fr, hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan)
+{
+    switch (fr) {
+    case 0: launch_digits<Bn254Fr, Code>(stream, scalars, dig, n, plan); break;
+    case 1: launch_digits<Bls377Fr, Code>(stream, scalars, dig, n, plan); break;
+    default: launch_digits<Bls381Fr, Code>(stream, scalars, dig, n, plan); break;
+    }
+}
+
 // digits + level-1 histogram; returns false if the fused kernel does not apply (the caller then runs k_digits + k_part_hist)
 template <class Fr, class Code>
 bool launch_digits_hist(hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan, const SortGeom &g)
@@ -799,6 +809,17 @@ bool launch_digits_hist(hipStream_t stream, const void *scalars, Code *dig, u32 
     return true;
 }
 
+template <class Code>
+bool launch_digits_hist_for(unsigned fr, hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan,
+                            const SortGeom &g)
+{
+    switch (fr) {
+    case 0: return launch_digits_hist<Bn254Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
+    case 1: return launch_digits_hist<Bls377Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
+    default: return launch_digits_hist<Bls381Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
+    }
+}
+
 } // namespace
 
 namespace panda {
@@ -806,6 +827,7 @@ namespace panda {
 WindowPlan make_window_plan(unsigned total_bits, unsigned c)
 {
     WindowPlan p{};
+    if (c < 4) c = 4; // narrower windows would not fit MAX_WINDOWS
     p.W = (total_bits + c - 1) / c;
     const unsigned base = total_bits / p.W, rem = total_bits % p.W;
     unsigned lo = 0;
@@ -835,7 +857,7 @@ static WindowPlan safe_plan(unsigned c)
     return plan;
 }
 
-WindowPlan make_safe_window_plan(unsigned fr, unsigned c) { return fr == 0 ? safe_plan<Bn254Fr>(c) : safe_plan<Bls377Fr>(c); }
+WindowPlan make_safe_window_plan(unsigned fr, unsigned c) { return fr == 0 ? safe_plan<Bn254Fr>(c) : (fr == 1 ? safe_plan<Bls377Fr>(c) : safe_plan<Bls381Fr>(c)); }
 
 size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
 {
@@ -864,14 +886,8 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     u32 *d_sorted = (u32 *)arena.take(n * W * 4);
     if (!d_dig || !d_thist || !d_tpref || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
 
-    const bool fused = fr == 0 ? launch_digits_hist<Bn254Fr, uint16_t>(stream, scalars, d_dig, d_thist, n, plan, geom)
-                               : launch_digits_hist<Bls377Fr, uint16_t>(stream, scalars, d_dig, d_thist, n, plan, geom);
-    if (!fused) {
-        if (fr == 0)
-            launch_digits<Bn254Fr, uint16_t>(stream, scalars, d_dig, n, plan);
-        else
-            launch_digits<Bls377Fr, uint16_t>(stream, scalars, d_dig, n, plan);
-    }
+    const bool fused = launch_digits_hist_for<uint16_t>(fr, stream, scalars, d_dig, d_thist, n, plan, geom);
+    if (!fused) launch_digits_for<uint16_t>(fr, stream, scalars, d_dig, n, plan);
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     if (!fused) hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
     hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_tpref, d_ptot, geom);
@@ -951,14 +967,8 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
         !d_off || !d_sorted)
         return hipErrorOutOfMemory;
 
-    const bool fused = fr == 0 ? launch_digits_hist<Bn254Fr, u32>(stream, scalars, d_dig, d_thist1, n, plan, g1)
-                               : launch_digits_hist<Bls377Fr, u32>(stream, scalars, d_dig, d_thist1, n, plan, g1);
-    if (!fused) {
-        if (fr == 0)
-            launch_digits<Bn254Fr, u32>(stream, scalars, d_dig, n, plan);
-        else
-            launch_digits<Bls377Fr, u32>(stream, scalars, d_dig, n, plan);
-    }
+    const bool fused = launch_digits_hist_for<u32>(fr, stream, scalars, d_dig, d_thist1, n, plan, g1);
+    if (!fused) launch_digits_for<u32>(fr, stream, scalars, d_dig, n, plan);
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     // level 1, per window
     if (!fused) hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);

@@ -622,6 +622,19 @@ panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1
         ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
 }
 
+// BLS12-381 Fr (two-adicity 32)
+panda_error panda_ntt_execute_bls12_381_v1(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false));
+}
+
+panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+}
+
 panda_error panda_ntt_tear_down(void)
 {
     std::lock_guard<std::mutex> lock(g_omega_mutex);

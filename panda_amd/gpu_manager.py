@@ -21,9 +21,14 @@ from . import gpu_ffi as ffi
 from .gpu_ffi import JACOBIAN, PROJECTIVE, PandaGpuError  # noqa: F401
 
 FIELD_ELEMENT_LEN = 32  # gpu_manager/mod.rs:14
-BN254, BLS12_377 = 0, 1
-_POINT_BYTES = {BN254: 64, BLS12_377: 96}
-_RESULT_BYTES = {BN254: 96, BLS12_377: 144}
+BN254, BLS12_377, BLS12_381 = 0, 1, 2
+_POINT_BYTES = {BN254: 64, BLS12_377: 96, BLS12_381: 96}
+_RESULT_BYTES = {BN254: 96, BLS12_377: 144, BLS12_381: 144}
+
+
+def _msm_entry(lib, curve: int, host: bool = False):
+    names = {BN254: "bn254", BLS12_377: "bls12_377", BLS12_381: "bls12_381"}
+    return getattr(lib, f"panda_msm_execute_{names[curve]}" + ("_host" if host else ""))
 
 
 def log_2(num: int) -> int:  # gpu_manager/common.rs:5-15
@@ -242,7 +247,7 @@ def _msm_device(gm, d_scalars, d_bases, log_n, curve, free_scalars, free_bases):
     d_result = _pool_alloc(gm, nres, gm.h2d_stream)
     gm.wait_h2d()
     cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d_bases, d_scalars, d_result, log_n, gm.msm_result_coordinate_type)
-    fn = lib.panda_msm_execute_bn254 if curve == BN254 else lib.panda_msm_execute_bls12_377
+    fn = _msm_entry(lib, curve)
     ffi.check(fn(cfg), "SchedulingErr")
     ev = PandaEventHandle()
     ev.record(gm.exec_stream)
@@ -299,7 +304,7 @@ def panda_msm_bn254_gpu_with_cached_bases_batched(gm: PandaGpuManager, scalars_b
     log_n = log_2(size // FIELD_ELEMENT_LEN)
     lib = ffi.load()
     nres = _RESULT_BYTES[curve]
-    fn = lib.panda_msm_execute_bn254 if curve == BN254 else lib.panda_msm_execute_bls12_377
+    fn = _msm_entry(lib, curve)
     slots, results = [], []
     try:
         for _ in range(min(2, len(batches))):
@@ -368,7 +373,7 @@ def panda_msm_bn254_gpu_host(gm, scalars, bases, curve: int = BN254) -> np.ndarr
     out = np.zeros(_RESULT_BYTES[curve], dtype=np.uint8)
     coord = gm.msm_result_coordinate_type if gm is not None else JACOBIAN
     cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), _ptr(b), _ptr(s), _ptr(out), log_2(s.size // FIELD_ELEMENT_LEN), coord)
-    fn = lib.panda_msm_execute_bn254_host if curve == BN254 else lib.panda_msm_execute_bls12_377_host
+    fn = _msm_entry(lib, curve, host=True)
     ffi.check(fn(cfg), "SchedulingErr")
     return out
 
@@ -401,6 +406,12 @@ def panda_ntt_bn254_gpu(gm: PandaGpuManager, scalars: np.ndarray, log_n: int) ->
 def panda_ntt_bn254_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int) -> int:
     """unit.rs:481-543."""
     return _ntt(gm, scalars, log_n, ffi.load().panda_ntt_execute_bn254_v1, omega)
+
+
+def panda_ntt_bls12_381_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:
+    """Additive: the v1 transform over the BLS12-381 scalar field (two-adicity 32)."""
+    lib = ffi.load()
+    return _ntt(gm, scalars, log_n, lib.panda_ntt_execute_bls12_381_inverse if inverse else lib.panda_ntt_execute_bls12_381_v1, omega)
 
 
 def panda_ntt_bls12_377_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:

@@ -15,16 +15,16 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "oracle")
 _SO = os.path.join(_DIR, "libpanda_oracle.so")
 
-BN254, BLS12_377 = 0, 1
-F_BN254_FQ, F_BN254_FR, F_BLS377_FQ, F_BLS377_FR = 0, 1, 2, 3
+BN254, BLS12_377, BLS12_381 = 0, 1, 2
+F_BN254_FQ, F_BN254_FR, F_BLS377_FQ, F_BLS377_FR, F_BLS381_FQ, F_BLS381_FR = 0, 1, 2, 3, 4, 5
 OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_TO_MONT, OP_FROM_MONT, OP_INV = range(7)
 COP_MADD, COP_ADD, COP_DBL = range(3)
 
-LC_Q = {BN254: 8, BLS12_377: 12}
-LC_R = {BN254: 8, BLS12_377: 8}
-FIELD_LC = {F_BN254_FQ: 8, F_BN254_FR: 8, F_BLS377_FQ: 12, F_BLS377_FR: 8}
-FQ_OF = {BN254: F_BN254_FQ, BLS12_377: F_BLS377_FQ}
-FR_OF = {BN254: F_BN254_FR, BLS12_377: F_BLS377_FR}
+LC_Q = {BN254: 8, BLS12_377: 12, BLS12_381: 12}
+LC_R = {BN254: 8, BLS12_377: 8, BLS12_381: 8}
+FIELD_LC = {F_BN254_FQ: 8, F_BN254_FR: 8, F_BLS377_FQ: 12, F_BLS377_FR: 8, F_BLS381_FQ: 12, F_BLS381_FR: 8}
+FQ_OF = {BN254: F_BN254_FQ, BLS12_377: F_BLS377_FQ, BLS12_381: F_BLS381_FQ}
+FR_OF = {BN254: F_BN254_FR, BLS12_377: F_BLS377_FR, BLS12_381: F_BLS381_FR}
 
 
 def build(force: bool = False) -> str:

@@ -61,7 +61,7 @@ def test_missing_library_fails_loudly(monkeypatch):
         ffi.load()
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_host_debug_entry_point(cid):
     """panda_msm_execute_bn254_host (panda_interface.cu:162-165 -> msm_host.cuh:267-383): all-host pointers."""
     for k, coord in ((10, pgm.JACOBIAN), (11, pgm.PROJECTIVE)):
@@ -74,7 +74,7 @@ def test_host_debug_entry_point(cid):
         lib = ffi.load()
         out = np.zeros(3 * po.LC_Q[cid], dtype=np.uint32)
         cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), bases.ctypes.data, scalars.ctypes.data, out.ctypes.data, k, coord)
-        fn = lib.panda_msm_execute_bn254_host if cid == 0 else lib.panda_msm_execute_bls12_377_host
+        fn = (lib.panda_msm_execute_bn254_host, lib.panda_msm_execute_bls12_377_host, lib.panda_msm_execute_bls12_381_host)[cid]
         assert fn(cfg) == 0
         got = po.hom_to_affine(cid, out) if coord == pgm.PROJECTIVE else po.to_affine(cid, out)
         assert (got == po.msm_affine(cid, bases, scalars, window_bits=9)).all()
@@ -82,7 +82,7 @@ def test_host_debug_entry_point(cid):
     assert fn(ffi.MSMConfiguration()) != 0  # null pointers are rejected with an error code, not a crash
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_combine_partials(cid):
     n = 1 << 10
     bases = po.gen_bases(cid, 900, n)

@@ -12,6 +12,7 @@ import pyref
 from gpu_util import NULL_STREAM, DeviceBuffer
 from panda_amd import gpu_ffi as ffi
 from panda_amd import gpu_manager as pgm
+from panda_amd import multi_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +31,7 @@ def affine_of(cid, result_bytes, coord=pgm.JACOBIAN):
 
 # ------------------------------------------------------------------ building blocks
 
-@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("fid", [0, 1, 2, 3, 4, 5])
 def test_field_ops_elementwise(fid):
     lc = po.FIELD_LC[fid]
     n = 1 << 14
@@ -50,7 +51,7 @@ def test_field_ops_elementwise(fid):
         d.free()
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_curve_ops_elementwise(cid):
     lc = po.LC_Q[cid]
     n = 512
@@ -89,7 +90,7 @@ def test_curve_ops_elementwise(cid):
     same(run(2, jac, jac), po.curve_vec(cid, po.COP_DBL, jac))
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_device_generators_match_oracle(cid):
     n = 3000
     lib = ffi.load()
@@ -254,7 +255,7 @@ def _msm_on_device_inputs(gm, cid, k, seed_b, seed_s):
     ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
     ffi.check(lib.panda_gen_scalars(cid, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
     cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
-    fn = lib.panda_msm_execute_bn254 if cid == 0 else lib.panda_msm_execute_bls12_377
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[cid]
     ffi.check(fn(cfg), "msm")
     out = dr.to_host()
     scalars = ds.to_host().reshape(n, 8)
@@ -401,7 +402,7 @@ def test_msm_baseline_full_sizes(gm, cid, k, coord):
     ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
     ffi.check(lib.panda_gen_scalars(cid, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
     cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, coord)
-    ffi.check((lib.panda_msm_execute_bn254 if cid == 0 else lib.panda_msm_execute_bls12_377)(cfg), "msm")
+    ffi.check((lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[cid](cfg), "msm")
     out = dr.to_host()
     scalars = ds.to_host().reshape(n, 8)
     for d in (db, ds, dr):
@@ -438,7 +439,7 @@ def test_committed_golden_fixtures(gm, golden_dir):
 def test_msm_tiny_sizes(gm, k):
     """n = 1 ... 512: degenerate geometry (one tile, one chunk, a single partition)."""
     n = 1 << k
-    for cid in (0, 1):
+    for cid in (0, 1, 2):
         bases = po.gen_bases(cid, 900 + k, n)
         scalars = po.gen_scalars(po.FR_OF[cid], 950 + k, n)
         out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
@@ -621,7 +622,7 @@ def _msm_precomputed_on_device(gm, cid, k, wbits, seed_b, seed_s):
     tables, bits = C.c_uint(0), C.c_uint(0)
     ffi.check(lib.panda_msm_registered_info(db.ptr, C.byref(tables), C.byref(bits), None), "info")
     cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
-    fn = lib.panda_msm_execute_bn254 if cid == 0 else lib.panda_msm_execute_bls12_377
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[cid]
     ffi.check(fn(cfg), "msm")
     out = dr.to_host()
     scalars = ds.to_host().reshape(n, 8)
@@ -699,10 +700,92 @@ def test_msm_ragged_lengths_and_bad_arguments(gm):
         assert lib.panda_msm_execute_bn254(cfg) == 1
         assert lib.panda_msm_execute_bls12_377(cfg) == 1
     assert lib.panda_msm_precompute_bases(0, None, 10, 0, gm.exec_stream.raw) == 1
-    assert lib.panda_msm_precompute_bases(2, d.ptr, 10, 0, gm.exec_stream.raw) == 1
+    assert lib.panda_msm_precompute_bases(3, d.ptr, 10, 0, gm.exec_stream.raw) == 1  # curve ids are 0, 1, 2
     assert lib.panda_msm_precompute_bases(0, d.ptr, 3, 30, gm.exec_stream.raw) == 1
     assert lib.panda_msm_register_bases(0, d.ptr, 27, gm.exec_stream.raw) == 1
     flag = C.c_uint(0)
     bad = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, None, d.ptr, None, 4, C.pointer(flag))
     assert lib.panda_ntt_execute_bn254_v1(bad) == 1
     d.free()
+
+
+# ------------------------------------------------------------------ BLS12-381 (the curve the reference names in curve.cuh:12)
+
+@pytest.mark.parametrize("k", [10, 13])
+def test_msm_bls12_381(gm, k):
+    """G1 MSM, device and host entry points, Jacobian and homogeneous output."""
+    cid = pgm.BLS12_381
+    n = 1 << k
+    bases = po.gen_bases(cid, 1500 + k, n)
+    scalars = po.gen_scalars(po.F_BLS381_FR, 1600 + k, n)
+    keep = scalars.copy()
+    want = po.expected_from_linearity(cid, 1500 + k, scalars)
+    for coord in (pgm.JACOBIAN, pgm.PROJECTIVE):
+        gm.set_config(coord)
+        try:
+            out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
+        finally:
+            gm.set_config(pgm.JACOBIAN)
+        assert out.size == 144
+        assert (affine_of(cid, out, coord) == want).all()
+    assert (scalars == keep).all()
+    if k == 10:
+        assert (want == po.msm_affine(cid, bases, scalars, window_bits=8)).all()
+        host = pgm.panda_msm_bn254_gpu_host(gm, scalars, bases, curve=cid)
+        assert (affine_of(cid, host) == want).all()
+
+
+@pytest.mark.parametrize("wbits", [0, 14])
+def test_msm_bls12_381_precomputed_tables_and_edges(gm, wbits):
+    cid = pgm.BLS12_381
+    n = 1 << 12
+    c = pyref.CURVES[cid]
+    bases = po.gen_bases(cid, 1700, n)
+    bases[3::7, :12] = 0  # identity bases
+    bases[301] = bases[300]
+    bases[301, 12:] = po.f_vec(po.F_BLS381_FQ, po.OP_SUB, np.zeros((1, 12), np.uint32), bases[300:301, 12:])[0]  # P, -P
+    scalars = po.gen_scalars(po.F_BLS381_FR, 1701, n)
+    scalars[301] = scalars[300]
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    for i, v in enumerate([0, 1, c.r - 1, 0xBEEF, (1 << 254) + 5]):
+        scalars[10 + i] = mont(v % c.r)
+    want = po.msm_affine(cid, bases, scalars, window_bits=9)
+    idx = gm.add_cached_bases(bases)
+    tables, bits, held = gm.precompute_cached_bases(idx, curve=cid, window_bits=wbits)
+    assert tables >= 2 and held == tables * n * 96
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=cid)
+    assert (affine_of(cid, out) == want).all()
+    out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
+    assert (affine_of(cid, out) == want).all()
+
+
+def test_msm_bls12_381_2_18_linearity(gm):
+    out, scalars = _msm_on_device_inputs(gm, 2, 18, 0x70616E6461 ^ 6, 0x5CA1A9)
+    assert (po.to_affine(2, out) == po.expected_from_linearity(2, 0x70616E6461 ^ 6, scalars)).all()
+    out, scalars, tables, bits = _msm_precomputed_on_device(gm, 2, 18, 0, 0x70616E6461 ^ 6, 0x5CA1AA)
+    assert tables >= 2
+    assert (po.to_affine(2, out) == po.expected_from_linearity(2, 0x70616E6461 ^ 6, scalars)).all()
+
+
+@pytest.mark.parametrize("log_n", [0, 3, 8, 11, 17, 20])
+def test_ntt_bls12_381_fr(gm, log_n):
+    """The NTT kernels over the BLS12-381 scalar field (two-adicity 32, headroom R/p = 70: the earliest reductions)."""
+    fid = po.F_BLS381_FR
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 4100 + log_n, 1 << log_n)
+    buf = x.copy()
+    pgm.panda_ntt_bls12_381_gpu_v1(gm, buf, om, log_n)
+    assert (buf == po.ntt(fid, x, om, log_n)).all()
+    pgm.panda_ntt_bls12_381_gpu_v1(gm, buf, om, log_n, inverse=True)
+    assert (buf == x).all()
+
+
+def test_msm_combine_bls12_381(gm):
+    """multi-GPU half: the sum of two range partials equals the whole MSM."""
+    cid = pgm.BLS12_381
+    n = 1 << 11
+    bases = po.gen_bases(cid, 1800, n)
+    scalars = po.gen_scalars(po.F_BLS381_FR, 1801, n)
+    parts = np.stack([pgm.panda_msm_bn254_gpu(gm, scalars[h * (n // 2):(h + 1) * (n // 2)], bases[h * (n // 2):(h + 1) * (n // 2)], curve=cid).view(np.uint32) for h in range(2)])
+    total = multi_gpu.combine_partials(parts, curve=cid)
+    assert (po.to_affine(cid, total.view(np.uint32)) == po.msm_affine(cid, bases, scalars, window_bits=9)).all()

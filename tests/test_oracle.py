@@ -53,9 +53,9 @@ def test_bls12_377_tables_match_reference_text():
     assert nums[25:37] == [int(x) for x in fq["r2"]]
 
 
-@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("fid", [0, 1, 2, 3, 4, 5])
 def test_field_ops_vs_python(fid):
-    cid, which = {0: (0, "p"), 1: (0, "r"), 2: (1, "p"), 3: (1, "r")}[fid]
+    cid, which = {0: (0, "p"), 1: (0, "r"), 2: (1, "p"), 3: (1, "r"), 4: (2, "p"), 5: (2, "r")}[fid]
     mod = getattr(pyref.CURVES[cid], which)
     lc = po.FIELD_LC[fid]
     R = (1 << (32 * lc)) % mod
@@ -80,7 +80,7 @@ def test_field_ops_vs_python(fid):
             assert x * y % mod == R * R % mod  # (xR)^-1 in Montgomery form: x^-1 R
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_generators_on_curve(cid):
     c = pyref.CURVES[cid]
     assert pyref.is_on_curve(c, c.g)
@@ -90,7 +90,7 @@ def test_generators_on_curve(cid):
     assert pyref.ec_mul(c, c.r, c.g) is None
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_group_law_vs_python(cid):
     c = pyref.CURVES[cid]
     lc = c.lc_q
@@ -149,7 +149,7 @@ def test_k13_fixture_files_equal_reference(golden_dir):
         assert open(os.path.join(golden_dir, ours), "rb").read() == open(f"{REF}/test/data/msm/k13/{theirs}", "rb").read()
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_msm_vs_python_and_naive(cid):
     c = pyref.CURVES[cid]
     n = 48
@@ -171,7 +171,7 @@ def test_msm_vs_python_and_naive(cid):
     assert (po.msm_affine(cid, bases, scalars, window_bits=11, threads=4) == want).all()
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_generated_bases_and_linearity(cid):
     c = pyref.CURVES[cid]
     n = 300
@@ -201,9 +201,9 @@ def test_msm_all_zero_scalars_gives_identity():
     assert not aff[:8].any() and (aff[8:] == po.field_info(0)["one"]).all()
 
 
-@pytest.mark.parametrize("fid", [po.F_BN254_FR, po.F_BLS377_FR])
+@pytest.mark.parametrize("fid", [po.F_BN254_FR, po.F_BLS377_FR, po.F_BLS381_FR])
 def test_ntt_definition(fid):
-    cid = 0 if fid == po.F_BN254_FR else 1
+    cid = {po.F_BN254_FR: 0, po.F_BLS377_FR: 1, po.F_BLS381_FR: 2}[fid]
     c = pyref.CURVES[cid]
     for log_n in (0, 1, 3, 6):
         n = 1 << log_n
