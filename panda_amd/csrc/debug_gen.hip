@@ -12,6 +12,30 @@ using namespace panda29;
 
 namespace {
 
+// Out-of-line copies of the heavy group operations for the 14-limb fields: these diagnostic kernels are not timed, and
+// inlining every operation for every curve made this file the longest compile of the library.
+template <class F>
+__device__ __noinline__ void to_affine_outlined(Fe<F> &x, Fe<F> &y, const Xyzz<F> &p)
+{
+    xyzz_to_affine_internal(x, y, p);
+}
+template <class F>
+__device__ __noinline__ void madd_outlined(Xyzz<F> &acc, const Fe<F> &x, const Fe<F> &y, bool inf)
+{
+    xyzz_madd(acc, x, y, inf);
+}
+template <class F>
+__device__ __noinline__ void add_outlined(Xyzz<F> &acc, const Xyzz<F> &q)
+{
+    xyzz_add(acc, q);
+}
+template <class F>
+__device__ __noinline__ void dbl_outlined(Xyzz<F> &r, const Xyzz<F> &p)
+{
+    xyzz_dbl(r, p);
+}
+
+
 template <class F>
 __global__ void __launch_bounds__(256) k_field_op(unsigned op, u32 *__restrict__ r, const u32 *__restrict__ a, const u32 *__restrict__ b, size_t n)
 {
@@ -62,14 +86,14 @@ __global__ void __launch_bounds__(128) k_curve_op(unsigned op, u32 *__restrict__
         for (int k = 0; k < 2 * L; k++) wb[k] = b[i * 2 * L + k];
         Fe<F> x, y;
         bool inf = affine_from_wire(x, y, wb);
-        xyzz_madd(p, x, y, inf);
+        madd_outlined(p, x, y, inf);
     } else if (op == 1) {
 #pragma unroll
         for (int k = 0; k < 3 * L; k++) wb[k] = b[i * 3 * L + k];
         xyzz_from_jacobian_wire(q, wb);
-        xyzz_add(p, q);
+        add_outlined(p, q);
     } else {
-        xyzz_dbl(q, p);
+        dbl_outlined(q, p);
         p = q;
     }
     xyzz_to_jacobian_wire(wr, p);
@@ -140,17 +164,17 @@ __global__ void k_gen_table(u32 *__restrict__ table, const u32 *__restrict__ gen
     Xyzz<F> acc, d;
     xyzz_from_affine(acc, bx, by);
     for (unsigned k = 0; k < 8 * j; k++) {
-        xyzz_dbl(d, acc);
+        dbl_outlined(d, acc);
         acc = d;
     }
     Fe<F> ax, ay;
-    xyzz_to_affine_internal(ax, ay, acc);
+    to_affine_outlined(ax, ay, acc);
     bx = ax;
     by = ay;
     xyzz_set_identity(acc);
     for (unsigned dgt = 1; dgt <= 255; dgt++) {
-        xyzz_madd(acc, bx, by, false);
-        xyzz_to_affine_internal(ax, ay, acc);
+        madd_outlined(acc, bx, by, false);
+        to_affine_outlined(ax, ay, acc);
         u32 *dst = table + ((size_t)j * 255 + (dgt - 1)) * 2 * N;
         for (int k = 0; k < N; k++) {
             dst[k] = ax.l[k];
@@ -178,11 +202,11 @@ __global__ void __launch_bounds__(128) k_gen_bases(u64 seed, u64 first, u64 n, c
             x.l[k] = src[k];
             y.l[k] = src[N + k];
         }
-        xyzz_madd(acc, x, y, false);
+        madd_outlined(acc, x, y, false);
     }
     Fe<F> ax, ay;
     u32 w[2 * L];
-    xyzz_to_affine_internal(ax, ay, acc);
+    to_affine_outlined(ax, ay, acc);
     fe_to_wire(w, ax);
     fe_to_wire(w + L, ay);
 #pragma unroll
