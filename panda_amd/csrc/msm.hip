@@ -137,7 +137,8 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
     if (curve > 2 || !d_bases || log_n > 26) return hipErrorInvalidValue;
     RegisteredBases r{};
     if (lookup_registered(r, d_bases, log_n, curve)) {
-        if (r.tabled == tabled && (!tabled || !window_bits || r.plan.width[0] == window_bits)) return hipSuccess;
+        if (!tabled && !r.tabled) return hipSuccess;
+        if (tabled && (r.tabled || log_n < 4)) return hipSuccess; // tables exist (or were not worth building)
         return hipErrorInvalidValue; // registered differently: unregister first
     }
     r = RegisteredBases{};
@@ -147,10 +148,11 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
     r.tabled = tabled;
     PANDA_TRY(hipGetDevice(&r.device));
     if (tabled) {
+        if (window_bits && (window_bits < 4 || window_bits > 24)) return hipErrorInvalidValue;
         const unsigned c = window_bits ? window_bits : pick_tabled_window_bits(curve, log_n);
-        if (c < 4 || c > 24) return hipErrorInvalidValue;
-        r.plan = panda::make_safe_window_plan(curve, c);
-        if (!panda::msm_sort_tabled_supported(log_n, r.plan)) return hipErrorInvalidValue;
+        if (c) r.plan = panda::make_safe_window_plan(curve, c);
+        // sizes the three-level sort has no geometry for (a handful of points) keep the converted copy only
+        if (!c || !panda::msm_sort_tabled_supported(log_n, r.plan)) r.tabled = false;
     }
     PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(r, s) : (curve == 1 ? panda::msm_build_registration_bls377(r, s) : panda::msm_build_registration_bls381(r, s)));
     std::lock_guard<std::mutex> lock(g_registry_mutex);

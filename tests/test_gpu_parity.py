@@ -789,3 +789,16 @@ def test_msm_combine_bls12_381(gm):
     parts = np.stack([pgm.panda_msm_bn254_gpu(gm, scalars[h * (n // 2):(h + 1) * (n // 2)], bases[h * (n // 2):(h + 1) * (n // 2)], curve=cid).view(np.uint32) for h in range(2)])
     total = multi_gpu.combine_partials(parts, curve=cid)
     assert (po.to_affine(cid, total.view(np.uint32)) == po.msm_affine(cid, bases, scalars, window_bits=9)).all()
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 6])
+def test_msm_precompute_tiny_base_sets(gm, k):
+    """A handful of points: precompute either builds tables or quietly keeps the converted copy; results are right either way."""
+    n = 1 << k
+    bases = po.gen_bases(0, 9950 + k, n)
+    scalars = po.gen_scalars(po.F_BN254_FR, 9960 + k, n)
+    idx = gm.add_cached_bases(bases)
+    tables, bits, held = gm.precompute_cached_bases(idx, curve=0)
+    assert tables >= 1 and held == tables * n * 64
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.to_affine(0, po.msm_naive(0, bases, scalars))).all()
