@@ -101,15 +101,18 @@ unsigned pick_window_bits(unsigned log_n)
 }
 
 // window width for precomputed tables: all windows share one bucket space, so wide windows are cheap --
-// minimise (additions) n * W(c) + (bucket reduction) ~8 * 2^(c-1) over the widths the sort supports
+// minimise (additions) n * W(c) + (bucket reduction) alpha * 2^(c-1) over the widths the sort supports.  A bucket costs
+// about 4 additions' worth of time when the reduction kernels are busy (2^23 points and up) and up to 13 when they are
+// latency-bound (measured: 2^20 is fastest at 17 bits, 2^22 at 20, 2^23 and 2^24 at 22).
 unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 {
+    const double alpha = log_n >= 23 ? 4.0 : (log_n >= 22 ? 8.0 : 13.0);
     unsigned best = 0;
     double best_cost = 0;
     for (unsigned c = 10; c <= 23; c++) {
         const panda::WindowPlan plan = panda::make_safe_window_plan(fr, c);
         if (plan.width[0] != c || !panda::msm_sort_tabled_supported(log_n, plan)) continue;
-        const double cost = (double)plan.W * (double)((u64)1 << log_n) + 8.0 * (double)(1u << (c - 1));
+        const double cost = (double)plan.W * (double)((u64)1 << log_n) + alpha * (double)(1u << (c - 1));
         if (!best || cost < best_cost) {
             best = c;
             best_cost = cost;

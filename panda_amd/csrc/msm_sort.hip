@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
 }
 
 constexpr unsigned K3_THREADS = 1024;
-constexpr unsigned K3_PER = 12;                     // words a thread keeps in registers
+constexpr unsigned K3_PER = 16;                     // words a thread keeps in registers
 constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once
 
 __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
@@ -768,6 +768,9 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
     g.log_n = log_n;
     g.W = plan.W;
     g.b3 = std::min(std::min(7u, 31u - log_n), B);
+    // a level-3 cell (2^b3 buckets of all windows) should fit k3_merge's register-resident path: mean entries per cell
+    // = W n 2^b3 / 2^B, kept below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars)
+    while (g.b3 > 3 && (((u64)plan.W << log_n) >> (B - g.b3)) > (u64)K3_CAP * 4 / 5) g.b3--;
     const unsigned rest = B - g.b3;
     g.b1 = (rest + 1) / 2;
     g.b2 = rest - g.b1;
