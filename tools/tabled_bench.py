@@ -1,5 +1,5 @@
 """Per-phase timing of the MSM with precomputed window tables against the plain registered path (development aid).
-usage: tabled_bench.py <log_n[,log_n..]> <window_bits[,..] (0 = policy)> <reduce_group[,..] (0 = policy)> [reps]"""
+usage: tabled_bench.py <log_n[,log_n..]> <window_bits[,..] (0 = policy)> <reduce_group[,..] (0 = policy)> [reps] [curve 0|1|2]"""
 import ctypes as C
 import os
 import sys
@@ -14,11 +14,12 @@ from panda_amd import gpu_ffi as ffi  # noqa: E402
 from panda_amd import gpu_manager as pgm  # noqa: E402
 
 
-def run(lib, cfg, reps, names):
+def run(lib, cfg, reps, names, fn=None):
+    fn = fn or lib.panda_msm_execute_bn254
     best = None
     for r in range(reps + 1):
         t = time.time()
-        ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        ffi.check(fn(cfg), "msm")
         dt = time.time() - t
         ms = (C.c_float * 8)()
         lib.panda_msm_last_phase_ms(ms)
@@ -33,28 +34,31 @@ def main():
     wbs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]
     groups = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0").split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    curve = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    pt, res = (64, 96) if curve == 0 else (96, 144)
     lib = ffi.load()
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[curve]
     gm = pgm.PandaGpuManager(0)
     names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
     for k in ks:
         n = 1 << k
-        db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
-        ffi.check(lib.panda_gen_bases(0, 1, 0, n, db.ptr, NULL_STREAM), "gen")
-        ffi.check(lib.panda_gen_scalars(0, 2, 0, n, ds.ptr, NULL_STREAM), "gen")
+        db, ds, dr = DeviceBuffer(n * pt), DeviceBuffer(n * 32), DeviceBuffer(res)
+        ffi.check(lib.panda_gen_bases(curve, 1, 0, n, db.ptr, NULL_STREAM), "gen")
+        ffi.check(lib.panda_gen_scalars(curve, 2, 0, n, ds.ptr, NULL_STREAM), "gen")
         cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, 0)
-        ffi.check(lib.panda_msm_register_bases(0, db.ptr, k, gm.exec_stream.raw), "register")
-        print(f"2^{k} plain registered      : " + run(lib, cfg, reps, names), flush=True)
+        ffi.check(lib.panda_msm_register_bases(curve, db.ptr, k, gm.exec_stream.raw), "register")
+        print(f"curve {curve} 2^{k} plain registered      : " + run(lib, cfg, reps, names, fn), flush=True)
         ref = dr.to_host().tobytes()
         ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
         for wb in wbs:
             t = time.time()
-            ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, k, wb, gm.exec_stream.raw), "precompute")
+            ffi.check(lib.panda_msm_precompute_bases(curve, db.ptr, k, wb, gm.exec_stream.raw), "precompute")
             tb = time.time() - t
             tables, bits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
             lib.panda_msm_registered_info(db.ptr, C.byref(tables), C.byref(bits), C.byref(held))
             for g in groups:
                 lib.panda_msm_set_reduce_group(g)
-                line = run(lib, cfg, reps, names)
+                line = run(lib, cfg, reps, names, fn)
                 same = "same-jacobian" if dr.to_host().tobytes() == ref else "different representative"
                 print(f"2^{k} tables c={bits.value:2d} W={tables.value:2d} group={g:2d} ({held.value/2**30:.1f} GiB, built in {tb:.2f}s): {line}  [{same}]", flush=True)
             lib.panda_msm_set_reduce_group(0)
