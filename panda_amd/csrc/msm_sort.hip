@@ -294,6 +294,57 @@ __global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__res
     }
 }
 
+// Tabled mode, level 1: the same scatter, but the word is stored split -- a u32 [b3 key bits][sign][point id], which is
+// exactly the word level 2 hands on, and a u8 with the b2 key bits level 2 partitions by.  Level 2 then counts from the
+// byte array alone and never moves more than five bytes per entry.
+template <class Code>
+__global__ void __launch_bounds__(SORT_THREADS) k1_scatter_split(const Code *__restrict__ dig, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
+                                                        const u32 *__restrict__ part_off, u32 *__restrict__ p1_lo, unsigned char *__restrict__ p1_hi, SortGeom g,
+                                                        unsigned b3)
+{
+    typedef CodeTraits<Code> CT;
+    __shared__ u32 lstart[MAX_PARTS];
+    __shared__ u32 lcur[MAX_PARTS];
+    __shared__ u32 gbase[MAX_PARTS];
+    __shared__ u32 words[SORT_TILE];
+    __shared__ unsigned char his[SORT_TILE];
+    __shared__ uint16_t parts_of[SORT_TILE];
+    __shared__ u32 scratch[SORT_THREADS];
+    const unsigned w = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const u64 row = ((u64)w * g.tiles + tile) * g.H;
+    const u32 *po = part_off + (u64)w * (g.H + 1);
+    for (unsigned i = tid; i < g.H; i += SORT_THREADS) {
+        lstart[i] = tile_hist[row + i];
+        lcur[i] = 0;
+        gbase[i] = po[i] + tile_pref[row + i];
+    }
+    __syncthreads();
+    const u64 n = (u64)1 << g.log_n;
+    const Code *dw = dig + ((u64)w << g.log_n);
+    u32 *plo = p1_lo + ((u64)w << g.log_n);
+    unsigned char *phi = p1_hi + ((u64)w << g.log_n);
+    const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+    const u32 b3_mask = (1u << b3) - 1, b2_mask = (1u << (g.lo_bits - b3)) - 1;
+    block_exclusive_scan(lstart, g.H, scratch);
+    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
+        u32 code = dw[i];
+        if (code == CT::ZERO) continue;
+        u32 b = code & CT::MAG, h = b >> g.lo_bits;
+        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
+        words[slot] = ((b & b3_mask) << (g.log_n + 1)) | ((code >> CT::SIGN) << g.log_n) | (u32)i;
+        his[slot] = (unsigned char)((b >> b3) & b2_mask);
+        parts_of[slot] = (uint16_t)h;
+    }
+    __syncthreads();
+    const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
+    for (u32 j = tid; j < total; j += SORT_THREADS) {
+        const u32 h = parts_of[j];
+        const u32 dst = gbase[h] + (j - lstart[h]);
+        plo[dst] = words[j];
+        phi[dst] = his[j];
+    }
+}
+
 // ---- plain mode, level 2: one workgroup per (partition, window) counts the lo values, publishes the bucket offsets,
 // then ranks the ids chunk by chunk in LDS and writes each chunk out as runs
 __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
@@ -479,8 +530,7 @@ __device__ __forceinline__ bool locate_tile(TileRange &r, unsigned tile, const u
     return true;
 }
 
-template <class Word>
-__global__ void __launch_bounds__(256) k2_hist(const Word *__restrict__ p1, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
+__global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
                                                u32 *__restrict__ tile_hist, TabledGeom g)
 {
     __shared__ u32 h[256];
@@ -489,9 +539,7 @@ __global__ void __launch_bounds__(256) k2_hist(const Word *__restrict__ p1, cons
     if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
     h[tid] = 0;
     __syncthreads();
-    const unsigned shift = g.log_n + 1 + g.b3;
-    const u32 mask = g.H2 - 1;
-    for (u64 i = r.begin + tid; i < r.end; i += 256) atomicAdd(&h[(u32)(p1[i] >> shift) & mask], 1u);
+    for (u64 i = r.begin + tid; i < r.end; i += 256) atomicAdd(&h[p1_hi[i]], 1u);
     __syncthreads();
     if (tid < g.H2) tile_hist[(u64)tile * g.H2 + tid] = h[tid];
 }
@@ -536,11 +584,10 @@ __global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals
     if (t == 255) sub_off[(u64)s * (g.H2 + 1) + g.H2] = tot[255];
 }
 
-// level-2 scatter: p1 words [b2][b3][sign][id] -> p2 words [b3][sign][id] (u32) grouped by b2 within the segment
-template <class Word>
-__global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const Word *__restrict__ p1, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
-                                                  const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref, const u32 *__restrict__ sub_off,
-                                                  u32 *__restrict__ p2, TabledGeom g)
+// level-2 scatter: the u32 halves of the level-1 words, grouped by their u8 halves within the segment
+__global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict__ p1_lo, const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off,
+                                                  const u32 *__restrict__ seg_tile, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
+                                                  const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g)
 {
     __shared__ u32 lstart[256], lcur[256];
     __shared__ u64 gbase[256];
@@ -556,15 +603,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const Word *__restric
         if (tid < g.H2) gbase[tid] = r.seg_begin + sub_off[(u64)r.s * (g.H2 + 1) + tid] + tile_pref[(u64)tile * g.H2 + tid];
     }
     __syncthreads();
-    const unsigned shift = g.log_n + 1 + g.b3;
-    const u32 mask = g.H2 - 1;
-    const Word keep = ((Word)1 << shift) - 1;
     block_exclusive_scan(lstart, g.H2, scratch);
     for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) {
-        const Word v = p1[i];
-        const u32 h = (u32)(v >> shift) & mask;
+        const u32 h = p1_hi[i];
         u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
-        words[slot] = (u32)(v & keep);
+        words[slot] = p1_lo[i];
         parts_of[slot] = (unsigned char)h;
     }
     __syncthreads();
@@ -783,7 +826,6 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
     return g;
 }
 
-bool tabled_wide_words(const TabledGeom &g) { return g.b2 + g.b3 + 1 + g.log_n > 32; }
 
 template <class Fr, class Code>
 void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan)
@@ -918,7 +960,7 @@ bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan)
     while ((1u << wbits) < plan.W) wbits++;
     if (log_n + wbits > 31) return false;
     const TabledGeom g = tabled_geom(log_n, plan);
-    return g.b1 <= 10 && g.b2 <= 8 && g.b3 <= 7 && g.S <= 16384 && g.b2 + g.b3 + 1 + log_n <= 64;
+    return g.b1 <= 10 && g.b2 <= 8 && g.b3 <= 7 && g.S <= 16384 && g.b3 + 1 + log_n <= 32;
 }
 
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
@@ -927,7 +969,7 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
     const unsigned NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
-    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 8) +
+    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4) + align256(E) +
            align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
            align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
            align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
@@ -941,7 +983,6 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     const u64 E = (u64)plan.W << log_n;
     const unsigned W = plan.W, NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
-    const bool wide = tabled_wide_words(g);
     SortGeom g1;
     g1.log_n = log_n;
     g1.lo_bits = g.b2 + g.b3;
@@ -954,7 +995,8 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     u32 *d_tpref1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     u32 *d_ptot = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
-    void *d_p1 = arena.take(E * (wide ? 8 : 4));
+    u32 *d_p1_lo = (u32 *)arena.take(E * 4);
+    unsigned char *d_p1_hi = (unsigned char *)arena.take(E);
     u32 *d_segtile = (u32 *)arena.take((size_t)(g.S + 1) * 4);
     u32 *d_thist2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
     u32 *d_tpref2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
@@ -966,7 +1008,7 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     u32 *d_celloff = (u32 *)arena.take((size_t)(g.Q + 1) * 4);
     u32 *d_off = (u32 *)arena.take((size_t)(NB + 1) * 4);
     u32 *d_sorted = (u32 *)arena.take(E * 4);
-    if (!d_dig || !d_thist1 || !d_tpref1 || !d_tpref2 || !d_poff || !d_ptot || !d_p1 || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum || !d_celloff ||
+    if (!d_dig || !d_thist1 || !d_tpref1 || !d_tpref2 || !d_poff || !d_ptot || !d_p1_lo || !d_p1_hi || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum || !d_celloff ||
         !d_off || !d_sorted)
         return hipErrorOutOfMemory;
 
@@ -977,22 +1019,13 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     if (!fused) hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);
     hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_tpref1, d_ptot, g1);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, g1);
-    if (wide)
-        hipLaunchKernelGGL((k_part_scatter<u32, u64>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, (u64 *)d_p1, g1);
-    else
-        hipLaunchKernelGGL((k_part_scatter<u32, u32>), dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, (u32 *)d_p1, g1);
+    hipLaunchKernelGGL(k1_scatter_split<u32>, dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, d_p1_lo, d_p1_hi, g1, g.b3);
     // level 2, per level-1 partition
     hipLaunchKernelGGL(k2_seg_tiles, dim3(1), dim3(SORT_THREADS), 0, stream, d_poff, d_segtile, g);
-    if (wide)
-        hipLaunchKernelGGL(k2_hist<u64>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, g);
-    else
-        hipLaunchKernelGGL(k2_hist<u32>, dim3(g.max_tiles2), dim3(256), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, g);
+    hipLaunchKernelGGL(k2_hist, dim3(g.max_tiles2), dim3(256), 0, stream, d_p1_hi, d_poff, d_segtile, d_thist2, g);
     hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, g.S), dim3(1024), 0, stream, d_thist2, d_tpref2, d_segtile, d_tot2, g);
     hipLaunchKernelGGL(k2_offsets, dim3(g.S), dim3(256), 0, stream, d_tot2, d_suboff, g);
-    if (wide)
-        hipLaunchKernelGGL(k2_scatter<u64>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u64 *)d_p1, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
-    else
-        hipLaunchKernelGGL(k2_scatter<u32>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, (const u32 *)d_p1, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
+    hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
     if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
     // level 3, per cell
     hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_suboff, d_cellcnt, d_blksum, g);

@@ -633,7 +633,7 @@ def _msm_precomputed_on_device(gm, cid, k, wbits, seed_b, seed_s):
 
 
 def test_msm_precomputed_tables_wide_words_2_18(gm):
-    """2^18 points with 22-bit windows: 2^21 shared buckets, 64-bit level-1 sort words."""
+    """2^18 points with 22-bit windows: 2^21 shared buckets (7 + 7 + 7 key bits over the three sort levels)."""
     out, scalars, tables, bits = _msm_precomputed_on_device(gm, 0, 18, 22, 0x70616E6461 ^ 7, 0x5CA1A7)
     assert bits == 22 and tables == 12
     assert (po.to_affine(0, out) == po.expected_from_linearity(0, 0x70616E6461 ^ 7, scalars)).all()
