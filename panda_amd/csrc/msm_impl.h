@@ -704,7 +704,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const unsigned lists = tabled ? 1u : W;         // independent bucket spaces
     const u64 stride = tabled ? (u64)W << log_n : n; // entries per list (upper bound)
     const unsigned lg = floor_log2(stride);
-    const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16)); // sorted entries per accumulate thread
+    // sorted entries per accumulate thread (64 ... 256 measure the same at 2^24: fewer pieces to merge against fewer threads)
+    const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16));
     const unsigned chunks = (unsigned)((stride + K - 1) / K);
     unsigned log_group = NB >= (1u << 18) ? 3u : 2u; // log2 of the buckets per k_reduce_groups thread
     if (tuning.reduce_group) log_group = floor_log2(tuning.reduce_group);
