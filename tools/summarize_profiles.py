@@ -10,6 +10,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GATHER_KERNELS = {"k_accumulate"}  # dominated by 64-byte row gathers
+GATHER_FACTOR = 1.0
 
 
 def latest(pattern):
@@ -38,10 +40,13 @@ def main():
             continue
         fv, wv = res["fetch"][k], res["write"].get(k, [0])
         f, w = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
-        rows.append((k, len(fv), f, 2 * f, w, 2 * f + w))
+        # FETCH_SIZE tallies a 128-byte request of a wide streaming read at 64 bytes (factor 2, MI355X_MICROARCH.md) but a
+        # 64-byte row gather exactly (factor 1: tools/ubench_gather.hip, profiles/*_fetch_size_calibration.txt)
+        factor = GATHER_FACTOR if k in GATHER_KERNELS else 2.0
+        rows.append((k, len(fv), f, factor * f, w, factor * f + w))
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_bytes.csv"), "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt --no-compare (BN254 MSM 2^24, precomputed tables)\n")
-        o.write("# bytes per launch = counter (KB) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane reads);\n")
+        o.write("# bytes per launch = counter (KB) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane streaming reads),\n# except k_accumulate: its reads are 64-byte row gathers, which the counter tallies exactly (calibrated with tools/ubench_gather.hip: 4.295 GB requested, 4.295 GB counted);\n")
         o.write("# k_convert_bases calibrates the correction: it reads 2^24 * 64 B = 1.074 GB\n")
         o.write("kernel,launches,fetch_size_raw_bytes,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
         for r in rows:
