@@ -802,3 +802,35 @@ def test_msm_precompute_tiny_base_sets(gm, k):
     assert tables >= 1 and held == tables * n * 64
     out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
     assert (affine_of(0, out) == po.to_affine(0, po.msm_naive(0, bases, scalars))).all()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_msm_precomputed_tables_random_geometry(gm, seed):
+    """Random (size, window width, scalar pattern) combinations: every split of the bucket id over the three sort levels, ragged
+    level-2 segments, empty windows, cells of every size."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(4, 15))
+    n = 1 << k
+    wbits = int(rng.choice([0, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22]))
+    c = pyref.CURVES[0]
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    pattern = int(rng.integers(0, 5))
+    scalars = po.gen_scalars(po.F_BN254_FR, 5000 + seed, n)
+    if pattern == 1:  # most scalars zero
+        scalars[rng.random(n) < 0.9] = 0
+    elif pattern == 2:  # small scalars: the high windows are empty
+        scalars = np.stack([mont(int(v)) for v in rng.integers(0, 1 << 40, n)])
+    elif pattern == 3:  # a few distinct values: huge buckets
+        vals = [mont(int.from_bytes(rng.bytes(32), "little") % c.r) for _ in range(3)]
+        scalars = np.stack([vals[int(i)] for i in rng.integers(0, 3, n)])
+    elif pattern == 4:  # values just below r and just above 0: carries through every window
+        scalars = np.stack([mont((c.r - 1 - int(v)) % c.r if i % 2 else int(v)) for i, v in enumerate(rng.integers(0, 1 << 20, n))])
+    bases = po.gen_bases(0, 6000 + seed, n)
+    idx = gm.add_cached_bases(bases)
+    try:
+        tables, bits, held = gm.precompute_cached_bases(idx, curve=0, window_bits=wbits)
+    except ffi.PandaGpuError:
+        assert wbits and k + int(np.ceil(np.log2(np.ceil(256 / wbits)))) > 31  # only an impossible geometry may be refused
+        return
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.expected_from_linearity(0, 6000 + seed, scalars)).all(), (k, wbits, pattern, tables, bits)
