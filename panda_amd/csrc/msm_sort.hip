@@ -500,7 +500,18 @@ __global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__
     if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
     h[tid] = 0;
     __syncthreads();
-    for (u64 i = r.begin + tid; i < r.end; i += 256) atomicAdd(&h[p1_hi[i]], 1u);
+    // 16 entries per load: aligned 16-byte vectors from the vector that contains `begin` on; bytes outside the tile are
+    // skipped by index (the array is padded by 16 bytes, so the last vector may run past `end`)
+    const u64 first = r.begin & ~(u64)15;
+    for (u64 a = first + (u64)tid * 16; a < r.end; a += 256 * 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p1_hi + a);
+        const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const u64 i = a + j;
+            if (i >= r.begin && i < r.end) atomicAdd(&h[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu], 1u);
+        }
+    }
     __syncthreads();
     if (tid < g.H2) tile_hist[(u64)tile * g.H2 + tid] = h[tid];
 }
@@ -927,7 +938,7 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
     const unsigned NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
-    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4) + align256(E) +
+    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4) + align256(E + 16) +
            align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
            align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
            align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
@@ -954,7 +965,7 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     u32 *d_ptot = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     u32 *d_p1_lo = (u32 *)arena.take(E * 4);
-    unsigned char *d_p1_hi = (unsigned char *)arena.take(E);
+    unsigned char *d_p1_hi = (unsigned char *)arena.take(E + 16);
     u32 *d_segtile = (u32 *)arena.take((size_t)(g.S + 1) * 4);
     u32 *d_thist2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
     u32 *d_tpref2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
