@@ -576,11 +576,28 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
     }
     __syncthreads();
     block_exclusive_scan(lstart, g.H2, scratch);
-    for (u64 i = r.begin + tid; i < r.end; i += SORT_THREADS) {
-        const u32 h = p1_hi[i];
-        u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
-        words[slot] = p1_lo[i];
-        parts_of[slot] = (unsigned char)h;
+    // 16 entries per thread and step: one aligned 16-byte vector of keys and the four 16-byte vectors of words that go with
+    // it (both arrays are padded, entries outside the tile are skipped by index)
+    const u64 first = r.begin & ~(u64)15;
+    for (u64 a = first + (u64)tid * 16; a < r.end; a += (u64)SORT_THREADS * 16) {
+        const uint4 kv = *reinterpret_cast<const uint4 *>(p1_hi + a);
+        const u32 keys[4] = {kv.x, kv.y, kv.z, kv.w};
+        const uint4 *lo4 = reinterpret_cast<const uint4 *>(p1_lo + a);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 wv = lo4[q];
+            const u32 ws[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u64 i = a + 4 * q + j;
+                if (i >= r.begin && i < r.end) {
+                    const u32 h = (keys[q] >> (8 * j)) & 0xffu;
+                    const u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
+                    words[slot] = ws[j];
+                    parts_of[slot] = (unsigned char)h;
+                }
+            }
+        }
     }
     __syncthreads();
     const u32 total = (u32)(r.end - r.begin);
@@ -938,7 +955,7 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
     const unsigned NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
-    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4) + align256(E + 16) +
+    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4 + 64) + align256(E + 16) +
            align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
            align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
            align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
@@ -964,7 +981,7 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     u32 *d_tpref1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
     u32 *d_ptot = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
-    u32 *d_p1_lo = (u32 *)arena.take(E * 4);
+    u32 *d_p1_lo = (u32 *)arena.take(E * 4 + 64);
     unsigned char *d_p1_hi = (unsigned char *)arena.take(E + 16);
     u32 *d_segtile = (u32 *)arena.take((size_t)(g.S + 1) * 4);
     u32 *d_thist2 = (u32 *)arena.take((size_t)g.max_tiles2 * g.H2 * 4);
