@@ -148,6 +148,23 @@ __global__ void __launch_bounds__(256) k_digits_hist(const u32 *__restrict__ sca
     }
 }
 
+// codes of window `dw` at positions [begin, end), 16 bytes per load (8 u16 or 4 u32 codes); begin is a multiple of the
+// tile size, the arrays are padded, codes past `end` are skipped by index.  f(index, code) for every code in range.
+template <class Code, class Fn>
+__device__ __forceinline__ void for_each_code(const Code *__restrict__ dw, u64 begin, u64 end, Fn f)
+{
+    constexpr unsigned PER = 16 / sizeof(Code);
+    for (u64 a = begin + (u64)threadIdx.x * PER; a < end; a += (u64)blockDim.x * PER) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(dw + a);
+        const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (unsigned j = 0; j < PER; j++) {
+            const u32 code = sizeof(Code) == 2 ? (wv[j >> 1] >> (16 * (j & 1))) & 0xffffu : wv[j];
+            if (a + j < end) f(a + j, code);
+        }
+    }
+}
+
 // ---- level 1 (both modes): per window, bucket id high bits -> partition ------------------------------------------
 // Bucket ids are split into `hi` (partition) and `lo` bits.  Level 1 moves every [lo][sign][point id] word into its
 // partition with per-tile LDS histograms and LDS cursors.  A partition's output range equals its input range, so no
@@ -168,10 +185,9 @@ __global__ void __launch_bounds__(256) k_part_hist(const Code *__restrict__ dig,
     const u64 n = (u64)1 << g.log_n;
     const Code *dw = dig + ((u64)w << g.log_n);
     const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
-    for (u64 i = begin + tid; i < end; i += 256) {
-        u32 code = dw[i];
+    for_each_code<Code>(dw, begin, end, [&](u64, u32 code) {
         if (code != CT::ZERO) atomicAdd(&h[(code & CT::MAG) >> g.lo_bits], 1u);
-    }
+    });
     __syncthreads();
     u32 *out = tile_hist + ((u64)w * g.tiles + tile) * g.H;
     for (unsigned i = tid; i < g.H; i += 256) out[i] = h[i];
@@ -277,14 +293,13 @@ __global__ void __launch_bounds__(SORT_THREADS) k_part_scatter(const Code *__res
     const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
     const u32 lo_mask = (1u << g.lo_bits) - 1;
     block_exclusive_scan(lstart, g.H, scratch);
-    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
-        u32 code = dw[i];
-        if (code == CT::ZERO) continue;
+    for_each_code<Code>(dw, begin, end, [&](u64 i, u32 code) {
+        if (code == CT::ZERO) return;
         u32 b = code & CT::MAG, h = b >> g.lo_bits;
         u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
         words[slot] = ((Word)(b & lo_mask) << (g.log_n + 1)) | (Word)(((code >> CT::SIGN) << g.log_n) | (u32)i);
         parts_of[slot] = (uint16_t)h;
-    }
+    });
     __syncthreads();
     const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
     for (u32 j = tid; j < total; j += SORT_THREADS) {
@@ -325,15 +340,14 @@ __global__ void __launch_bounds__(SORT_THREADS) k1_scatter_split(const Code *__r
     const u64 begin = (u64)tile * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
     const u32 b3_mask = (1u << b3) - 1, b2_mask = (1u << (g.lo_bits - b3)) - 1;
     block_exclusive_scan(lstart, g.H, scratch);
-    for (u64 i = begin + tid; i < end; i += SORT_THREADS) {
-        u32 code = dw[i];
-        if (code == CT::ZERO) continue;
+    for_each_code<Code>(dw, begin, end, [&](u64 i, u32 code) {
+        if (code == CT::ZERO) return;
         u32 b = code & CT::MAG, h = b >> g.lo_bits;
         u32 slot = lstart[h] + atomicAdd(&lcur[h], 1u);
         words[slot] = ((b & b3_mask) << (g.log_n + 1)) | ((code >> CT::SIGN) << g.log_n) | (u32)i;
         his[slot] = (unsigned char)((b >> b3) & b2_mask);
         parts_of[slot] = (uint16_t)h;
-    }
+    });
     __syncthreads();
     const u32 total = lstart[g.H - 1] + lcur[g.H - 1];
     for (u32 j = tid; j < total; j += SORT_THREADS) {
@@ -898,7 +912,7 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
     const SortGeom g = plain_geom(log_n, c);
-    return align256(n * W * 2) + 2 * align256((size_t)W * g.tiles * g.H * 4) + 2 * align256((size_t)W * (g.H + 1) * 4) + align256((size_t)W * (NB + 1) * 4) +
+    return align256(n * W * 2 + 16) + 2 * align256((size_t)W * g.tiles * g.H * 4) + 2 * align256((size_t)W * (g.H + 1) * 4) + align256((size_t)W * (NB + 1) * 4) +
            2 * align256(n * W * 4) + 4096;
 }
 
@@ -910,7 +924,7 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     if (c > 16 || c < 2) return hipErrorInvalidValue;
     const SortGeom geom = plain_geom(log_n, c);
     if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
-    uint16_t *d_dig = (uint16_t *)arena.take(n * W * 2);
+    uint16_t *d_dig = (uint16_t *)arena.take(n * W * 2 + 16);
     u32 *d_thist = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
     u32 *d_tpref = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (geom.H + 1) * 4);
@@ -955,7 +969,7 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
     const unsigned NB = 1u << (plan.width[0] - 1);
     const TabledGeom g = tabled_geom(log_n, plan);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
-    return align256(E * 4) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4 + 64) + align256(E + 16) +
+    return align256(E * 4 + 16) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4 + 64) + align256(E + 16) +
            align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
            align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
            align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
@@ -976,7 +990,7 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     g1.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
     const unsigned qblocks = (g.Q + 1023) / 1024;
 
-    u32 *d_dig = (u32 *)arena.take(E * 4);
+    u32 *d_dig = (u32 *)arena.take(E * 4 + 16);
     u32 *d_thist1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
     u32 *d_tpref1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
     u32 *d_poff = (u32 *)arena.take((size_t)W * (g.H1 + 1) * 4);
