@@ -358,12 +358,31 @@ __global__ void __launch_bounds__(SORT_THREADS) k1_scatter_split(const Code *__r
     }
 }
 
+// inclusive scan of cnt[0..127] in place by the first two waves of the block: shuffles inside a wave, one barrier
+// to pass wave 0's total on (instead of seven barrier-separated Hillis-Steele steps).  All threads must call it.
+__device__ __forceinline__ void scan128_inclusive(u32 *cnt, u32 *carry /* one LDS word */)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    u32 v = tid < 128 ? cnt[tid] : 0;
+    if (tid < 128) {
+        for (unsigned d = 1; d < 64; d <<= 1) {
+            const u32 up = __shfl_up(v, d, 64);
+            if (lane >= d) v += up;
+        }
+        if (tid == 63) *carry = v;
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128) v += *carry;
+    if (tid < 128) cnt[tid] = v;
+    __syncthreads();
+}
+
 // ---- plain mode, level 2: one workgroup per (partition, window) counts the lo values, publishes the bucket offsets,
 // then ranks the ids chunk by chunk in LDS and writes each chunk out as runs
 __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restrict__ p1, const u32 *__restrict__ part_off, u32 *__restrict__ off,
                                                      u32 *__restrict__ sorted, SortGeom g, unsigned NB)
 {
-    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128];
+    __shared__ u32 cnt[128], cur[128], lstart[128], lcur[128], scan_carry;
     __shared__ u32 words[BS_CHUNK];
     __shared__ unsigned char lo_of[BS_CHUNK];
     const unsigned w = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
@@ -377,12 +396,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restr
     for (u32 j = ps + tid; j < pe; j += SORT_THREADS) atomicAdd(&cnt[pw[j] >> shift], 1u);
     __syncthreads();
     u32 mine = tid < 128 ? cnt[tid] : 0;
-    for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
-        u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
-        __syncthreads();
-        if (tid < 128) cnt[tid] += v;
-        __syncthreads();
-    }
+    scan128_inclusive(cnt, &scan_carry);
     if (tid < L) {
         u32 start = ps + cnt[tid] - mine;
         cur[tid] = start;
@@ -401,12 +415,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restr
         for (u32 j = cbeg + tid; j < cend; j += SORT_THREADS) atomicAdd(&lstart[pw[j] >> shift], 1u);
         __syncthreads();
         u32 c0 = tid < 128 ? lstart[tid] : 0;
-        for (unsigned d = 1; d < 128; d <<= 1) {
-            u32 v = (tid < 128 && tid >= d) ? lstart[tid - d] : 0;
-            __syncthreads();
-            if (tid < 128) lstart[tid] += v;
-            __syncthreads();
-        }
+        scan128_inclusive(lstart, &scan_carry);
         if (tid < 128) {
             lstart[tid] -= c0; // exclusive
             cnt[tid] = c0;
@@ -688,7 +697,7 @@ constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many
 __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
                                               const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB)
 {
-    __shared__ u32 cnt[128], cur[128];
+    __shared__ u32 cnt[128], cur[128], scan_carry;
     __shared__ u32 outbuf[K3_CAP];
     __shared__ u64 rbegin[64];
     __shared__ u32 rlen[64];
@@ -732,11 +741,12 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         // (the cell's buckets are adjacent in the output)
         u32 word[K3_PER];
         unsigned char lo[K3_PER];
+        unsigned k = 0; // a thread's positions grow by K3_THREADS, about one run: the window only ever steps forward
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
             const u32 p = tid + j * K3_THREADS;
             if (p < N) {
-                const unsigned k = window_of(p);
+                while (p >= vstart[k + 1]) k++;
                 const u32 v = p2[rbegin[k] + (p - vstart[k])];
                 word[j] = final_word(v, k);
                 lo[j] = (unsigned char)(v >> shift);
@@ -745,12 +755,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         }
         __syncthreads();
         u32 mine = tid < 128 ? cnt[tid] : 0;
-        for (unsigned d = 1; d < 128; d <<= 1) { // inclusive scan of the (at most 128) counts
-            u32 v = (tid < 128 && tid >= d) ? cnt[tid - d] : 0;
-            __syncthreads();
-            if (tid < 128) cnt[tid] += v;
-            __syncthreads();
-        }
+        scan128_inclusive(cnt, &scan_carry);
         if (tid < L) {
             const u32 start = cnt[tid] - mine; // local
             cur[tid] = start;
