@@ -46,7 +46,8 @@ def main():
     msm = []
     for cid, k, kind, seed in [(0, 10, "uniform", 1), (0, 12, "uniform", 2), (0, 14, "uniform", 3), (1, 10, "uniform", 4), (1, 12, "uniform", 5),
                                (0, 11, "zeros", 6), (0, 11, "ones", 7), (0, 11, "minus_one", 8), (0, 11, "small16", 9), (0, 11, "all_equal", 10),
-                               (0, 11, "half_zero", 11), (1, 11, "minus_one", 12), (1, 11, "all_equal", 13)]:
+                               (0, 11, "half_zero", 11), (1, 11, "minus_one", 12), (1, 11, "all_equal", 13),
+                               (2, 10, "uniform", 14), (2, 12, "uniform", 15), (2, 11, "minus_one", 16), (2, 11, "small16", 17)]:
         n = 1 << k
         bases = po.gen_bases(cid, 0xB000 + seed, n)
         scalars = scalar_set(kind, cid, n, 0x5000 + seed)

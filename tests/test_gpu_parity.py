@@ -426,6 +426,11 @@ def test_committed_golden_fixtures(gm, golden_dir):
         out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
         assert affine_of(cid, out).tobytes().hex() == c["affine_hex"], c
         assert (not out.view(np.uint32)[2 * po.LC_Q[cid]:].any()) == c["identity"]
+        idx = gm.add_cached_bases(bases)  # the same fixture through the precomputed-table path
+        gm.precompute_cached_bases(idx, curve=cid)
+        out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=cid)
+        assert affine_of(cid, out).tobytes().hex() == c["affine_hex"], ("tables", c)
+        assert (not out.view(np.uint32)[2 * po.LC_Q[cid]:].any()) == c["identity"]
     for c in json.load(open(os.path.join(golden_dir, "ntt_cases.json"))):
         x = po.gen_scalars(po.F_BN254_FR, c["seed"], 1 << c["log_n"])
         om = np.frombuffer(bytes.fromhex(c["omega_hex"]), dtype=np.uint32).copy()
