@@ -178,6 +178,10 @@ const char *panda_msm_phase_name(unsigned phase);
 /* Inverse transform: runs the forward passes with omega^-1 and fuses the n^-1 scaling into the last pass.
  * d_omega is the FORWARD root (host pointer), as for _v1. */
 panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exec_cfg);
+/* Coset transforms (additive): forward y[k] = sum_j x[j] g^j w^(jk), inverse x[j] = g^-j n^-1 sum_k y[k] w^(-jk); `shift` is a HOST pointer
+ * to g in Montgomery form (32 bytes, non-zero), d_omega the forward root as for _v1.  In place on d_src/d_dst with the usual flag protocol. */
+panda_error panda_ntt_execute_bn254_coset(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
+panda_error panda_ntt_execute_bn254_coset_inverse(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
 /* The same transforms over the BLS12-377 scalar field (README.md:36: "easy to encapsulate ... BLS12-377 later") */
 panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 exec_cfg);
 panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1 exec_cfg);

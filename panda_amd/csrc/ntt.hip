@@ -495,6 +495,48 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     return hipSuccess;
 }
 
+// x[j] *= base^j, j < 2^log_n, in place (the coset shift of a coset NTT): two power tables and k_slab_twiddle
+template <class Fr>
+hipError_t scale_by_powers(hipStream_t stream, u32 *d_x, unsigned log_n, const Fe<Fr> &base)
+{
+    const u64 n = (u64)1 << log_n;
+    panda::Arena &arena = panda::thread_arena();
+    PANDA_TRY(arena.reserve(SZ_TA + SZ_TB + 4096));
+    u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB);
+    if (!d_ta || !d_tb) return hipErrorOutOfMemory;
+    build_table<Fr>(stream, base, nullptr, (unsigned)std::min<u64>(n, 1u << 16), d_ta);
+    if (log_n > 16) {
+        Fe<Fr> base_b;
+        fe_pow_u64(base_b, base, (u64)1 << 16);
+        build_table<Fr>(stream, base_b, nullptr, 1u << (log_n - 16), d_tb);
+    }
+    hipLaunchKernelGGL(k_slab_twiddle<Fr>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_x, d_ta, d_tb, (unsigned)n);
+    PANDA_TRY(hipGetLastError());
+    return hipStreamSynchronize(stream);
+}
+
+// Coset transforms: forward y[k] = sum_j x[j] g^j w^(jk) (evaluation on the coset g*H), inverse x[j] = g^-j n^-1 sum_k y[k] w^(-jk).
+// The shift is applied as one extra element-wise pass before (after) the passes of the plain transform.
+template <class Fr>
+hipError_t ntt_coset_run(const panda_ntt_configuration_v1 &cfg, const void *shift_wire, bool inverse)
+{
+    if (!shift_wire || !cfg.d_src || !cfg.d_dst || !cfg.d_omega || !cfg.flag || cfg.log_n > 28) return hipErrorInvalidValue;
+    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
+    Fe<Fr> g;
+    fe_from_wire(g, (const u32 *)shift_wire);
+    if (fe_is_zero_mod_p(g)) return hipErrorInvalidValue;
+    if (!inverse) {
+        PANDA_TRY(order_after_null_stream(stream));
+        PANDA_TRY(scale_by_powers<Fr>(stream, (u32 *)cfg.d_src, cfg.log_n, g));
+        return ntt_run<Fr>(stream, cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false);
+    }
+    PANDA_TRY(ntt_run<Fr>(stream, cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+    Fe<Fr> gi;
+    fe_inv(gi, g);
+    u32 *res = (*(unsigned *)cfg.flag & 1u) ? (u32 *)cfg.d_dst : (u32 *)cfg.d_src;
+    return scale_by_powers<Fr>(stream, res, cfg.log_n, gi);
+}
+
 // multi-GPU step 1: local transform of the rank's decimated slab + the inter-slab twiddle w^(rank * k2)
 template <class Fr>
 hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
@@ -608,6 +650,16 @@ panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 cfg
 panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg)); }
 
 panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg)); }
+
+panda_error panda_ntt_execute_bn254_coset(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bn254Fr>(cfg, shift, false));
+}
+
+panda_error panda_ntt_execute_bn254_coset_inverse(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bn254Fr>(cfg, shift, true));
+}
 
 // BLS12-377 Fr (two-adicity 47): same kernels, other field parameters
 panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 cfg)

@@ -408,6 +408,14 @@ def panda_ntt_bn254_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_
     return _ntt(gm, scalars, log_n, ffi.load().panda_ntt_execute_bn254_v1, omega)
 
 
+def panda_coset_ntt_bn254_gpu(gm: PandaGpuManager, scalars: np.ndarray, omega, shift, log_n: int, inverse: bool = False) -> int:
+    """Additive: coset transform, in place.  Forward y[k] = sum_j x[j] g^j w^(jk); inverse undoes it (n^-1 and g^-j fused)."""
+    lib = ffi.load()
+    g = _as_bytes(shift)
+    fn = lib.panda_ntt_execute_bn254_coset_inverse if inverse else lib.panda_ntt_execute_bn254_coset
+    return _ntt(gm, scalars, log_n, lambda cfg: fn(cfg, _ptr(g)), omega)
+
+
 def panda_ntt_bls12_381_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:
     """Additive: the v1 transform over the BLS12-381 scalar field (two-adicity 32)."""
     lib = ffi.load()

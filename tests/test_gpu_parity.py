@@ -839,3 +839,34 @@ def test_msm_precomputed_tables_random_geometry(gm, seed):
         return
     out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
     assert (affine_of(0, out) == po.expected_from_linearity(0, 6000 + seed, scalars)).all(), (k, wbits, pattern, tables, bits)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 5, 10, 16, 18])
+def test_coset_ntt_bn254(gm, log_n):
+    """Additive coset transforms: y = NTT(x[j] * g^j), checked against the oracle NTT of the pre-scaled input; the inverse
+    returns the original coefficients."""
+    fid = po.F_BN254_FR
+    c = pyref.CURVES[0]
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 4200 + log_n, n)
+    g = pyref.int_to_limbs(5 * c.Rr % c.r, 8)  # the shift 5 in Montgomery form
+    pw = np.empty((n, 8), np.uint32)
+    cur = pyref.int_to_limbs(c.Rr % c.r, 8)
+    gi = 5
+    acc = 1
+    for j in range(min(n, 1 << 12)):  # g^j in Montgomery form, by big-int arithmetic
+        pw[j] = pyref.int_to_limbs(acc * c.Rr % c.r, 8)
+        acc = acc * gi % c.r
+    if n > (1 << 12):  # the rest by oracle multiplications in blocks
+        step = pyref.int_to_limbs(pow(5, 1 << 12, c.r) * c.Rr % c.r, 8)
+        for b in range(1, n >> 12):
+            pw[b << 12:(b + 1) << 12] = po.f_vec(fid, po.OP_MUL, pw[(b - 1) << 12:b << 12], np.tile(step, (1 << 12, 1)))
+    scaled = po.f_vec(fid, po.OP_MUL, x, pw)
+    want = po.ntt(fid, scaled, om, log_n)
+    buf = x.copy()
+    pgm.panda_coset_ntt_bn254_gpu(gm, buf, om, g, log_n)
+    assert (buf == want).all()
+    pgm.panda_coset_ntt_bn254_gpu(gm, buf, om, g, log_n, inverse=True)
+    assert (buf == x).all()
+    del cur
