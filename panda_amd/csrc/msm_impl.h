@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
     load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
     for (u32 t = t0 + 1; t <= t1; t++) {
         load_xyzz<F>(q, pw + (u64)t * 2 * PW);
-        cold_add(acc, q);
+        xyzz_add(acc, q); // inlined for every field: k_fixup is throughput-relevant
     }
     store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
 }
@@ -422,9 +422,9 @@ __global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ b
         u32 b = g * group + j;
         if (b < NB) {
             load_xyzz<F>(q, bw + (u64)b * PW);
-            cold_add(run, q);
+            xyzz_add(run, q); // inlined for every field: k_reduce_groups does two additions per bucket
         }
-        cold_add(sum, run);
+        xyzz_add(sum, run);
     }
     store_xyzz<F>(gS + ((u64)w * groups + g) * PW, run);
     store_xyzz<F>(gT + ((u64)w * groups + g) * PW, sum);
