@@ -115,14 +115,15 @@ def main():
         # library keeps its radix-converted copy -- and, unless --no-tables, the window tables 2^lo[k]*P built from it --
         # instead of re-deriving them in every call.  Built before the timed region; depends on the bases only.
         t_reg = time.perf_counter()
-        if args.no_tables:
+        use_tables = not args.no_tables
+        if use_tables and lib.panda_msm_precompute_bases(0, bases.data_ptr(), log_n, 0, pstream) != 0:
+            use_tables = False  # e.g. not enough free HBM for the tables: fall back to the converted copy alone
+        if not use_tables:
             ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
-        else:
-            ffi.check(lib.panda_msm_precompute_bases(0, bases.data_ptr(), log_n, 0, pstream), "precompute_bases")
         t_reg = time.perf_counter() - t_reg
         tables, wbits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
         ffi.check(lib.panda_msm_registered_info(bases.data_ptr(), C.byref(tables), C.byref(wbits), C.byref(held)), "registered_info")
-        if args.no_tables:
+        if not use_tables:
             bases_mode = "cached: resident and registered (panda_msm_register_bases)"
         else:
             bases_mode = (f"cached: resident, registered with {tables.value} precomputed window tables of {wbits.value}-bit windows "
@@ -203,7 +204,7 @@ def main():
         }
         if world == 1:
             out["pcie_inclusive"] = pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n)
-            if not args.no_register and not args.no_tables and not args.no_compare:
+            if not args.no_register and not args.no_tables and not args.no_compare and tables.value > 1:
                 out["without_tables"] = without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, max(2, args.steps // 2))
         if not args.no_ntt:
             out["ntt"] = ntt_figure(lib, ffi, torch, dev, pstream)
