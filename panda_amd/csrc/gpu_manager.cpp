@@ -148,7 +148,7 @@ PandaGpuError PandaGpuManager::sync() const
 PandaGpuError PandaGpuManager::deinit()
 {
     for (void *p : registered_bases)
-        if (panda_msm_unregister_bases(p) != 0) return PandaGpuError::DestroyContextErr;
+        (void)panda_msm_unregister_bases(p); // "not registered" (the caller already undid it) is not an error here
     registered_bases.clear();
     for (void *p : d_bases)
         if (panda_free(p) != 0) return PandaGpuError::DestroyContextErr;
