@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #include "fe29.h"
+#include "fe29_chain.h"
 using namespace panda29;
 typedef Bn254Fq F;
 
@@ -40,6 +41,49 @@ __device__ __forceinline__ void fe_mul_asm(Fe<F> &r, const Fe<F> &a, const Fe<F>
     for (int i = 0; i < N; i++) r.l[i] = out[i];
 }
 
+// column-block variant: the multiply-adds of a column in one or two asm blocks (MacChain), no s_nop between them
+__device__ __forceinline__ void fe_mul_blk(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    constexpr int N = F::N;
+    u32 m[N], out[N];
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        switch (k) { // constant after unrolling
+        case 0: MacChain<1>::vv(acc, &a.l[0], &b.l[0]); break;
+        case 1: MacChain<2>::vv(acc, &a.l[0], &b.l[1]); MacChain<1>::vs(acc, &m[0], &F::P[1]); break;
+        case 2: MacChain<3>::vv(acc, &a.l[0], &b.l[2]); MacChain<2>::vs(acc, &m[0], &F::P[2]); break;
+        case 3: MacChain<4>::vv(acc, &a.l[0], &b.l[3]); MacChain<3>::vs(acc, &m[0], &F::P[3]); break;
+        case 4: MacChain<5>::vv(acc, &a.l[0], &b.l[4]); MacChain<4>::vs(acc, &m[0], &F::P[4]); break;
+        case 5: MacChain<6>::vv(acc, &a.l[0], &b.l[5]); MacChain<5>::vs(acc, &m[0], &F::P[5]); break;
+        case 6: MacChain<7>::vv(acc, &a.l[0], &b.l[6]); MacChain<6>::vs(acc, &m[0], &F::P[6]); break;
+        case 7: MacChain<8>::vv(acc, &a.l[0], &b.l[7]); MacChain<7>::vs(acc, &m[0], &F::P[7]); break;
+        default: MacChain<9>::vv(acc, &a.l[0], &b.l[8]); MacChain<8>::vs(acc, &m[0], &F::P[8]); break;
+        }
+        m[k] = ((u32)acc * F::INV) & LIMB_MASK;
+        mad_vs(acc, m[k], F::P[0]);
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+        switch (k) {
+        case 9: MacChain<8>::vv(acc, &a.l[1], &b.l[8]); MacChain<8>::vs(acc, &m[1], &F::P[8]); break;
+        case 10: MacChain<7>::vv(acc, &a.l[2], &b.l[8]); MacChain<7>::vs(acc, &m[2], &F::P[8]); break;
+        case 11: MacChain<6>::vv(acc, &a.l[3], &b.l[8]); MacChain<6>::vs(acc, &m[3], &F::P[8]); break;
+        case 12: MacChain<5>::vv(acc, &a.l[4], &b.l[8]); MacChain<5>::vs(acc, &m[4], &F::P[8]); break;
+        case 13: MacChain<4>::vv(acc, &a.l[5], &b.l[8]); MacChain<4>::vs(acc, &m[5], &F::P[8]); break;
+        case 14: MacChain<3>::vv(acc, &a.l[6], &b.l[8]); MacChain<3>::vs(acc, &m[6], &F::P[8]); break;
+        case 15: MacChain<2>::vv(acc, &a.l[7], &b.l[8]); MacChain<2>::vs(acc, &m[7], &F::P[8]); break;
+        default: MacChain<1>::vv(acc, &a.l[8], &b.l[8]); MacChain<1>::vs(acc, &m[8], &F::P[8]); break;
+        }
+        out[k - N] = (u32)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    out[N - 1] = (u32)acc;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+}
+
 #define ITERS 256
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in)
@@ -54,7 +98,8 @@ __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in)
     z = y; w = x; z.l[0] ^= 5; w.l[1] ^= 9;
     for (int it = 0; it < ITERS; it++) { // two independent chains, like the independent products inside a madd
         if (VARIANT == 0) { fe_mul(x, x, y); fe_mul(z, z, w); fe_mul(y, y, x); fe_mul(w, w, z); }
-        else { fe_mul_asm(x, x, y); fe_mul_asm(z, z, w); fe_mul_asm(y, y, x); fe_mul_asm(w, w, z); }
+        else if (VARIANT == 1) { fe_mul_asm(x, x, y); fe_mul_asm(z, z, w); fe_mul_asm(y, y, x); fe_mul_asm(w, w, z); }
+        else { fe_mul_blk(x, x, y); fe_mul_blk(z, z, w); fe_mul_blk(y, y, x); fe_mul_blk(w, w, z); }
     }
     u32 s = 0;
     for (int j = 0; j < 9; j++) s += x.l[j] * 3 + y.l[j] * 5 + z.l[j] * 7 + w.l[j] * 11;
@@ -87,6 +132,7 @@ int main()
         printf("--- %d waves/SIMD ---\n", wps);
         run<0>("compiler", blocks, out, in, &chk);
         run<1>("asm-chain", blocks, out, in, &chk);
+        run<2>("asm-block", blocks, out, in, &chk);
     }
     return 0;
 }
