@@ -305,23 +305,6 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     store_xyzz<F>(dst, acc);
 }
 
-// Point additions of the cold kernels (fix-up, bucket reduction).  For the 14-limb fields one addition is ~10 k
-// instructions; inlining it at twenty call sites makes the translation unit compile for many minutes, so those fields
-// call one out-of-line copy instead (these kernels are latency-bound, the call costs little).  BN254 stays inlined.
-template <class F>
-__device__ __noinline__ void xyzz_add_outlined(Xyzz<F> &acc, const Xyzz<F> &q)
-{
-    xyzz_add(acc, q);
-}
-template <class F>
-__device__ __forceinline__ void cold_add(Xyzz<F> &acc, const Xyzz<F> &q)
-{
-    if constexpr (F::N > 9)
-        xyzz_add_outlined(acc, q);
-    else
-        xyzz_add(acc, q);
-}
-
 // bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
 // also is t0's first run and started earlier -- impossible here since t0 = start / K), the ONLY run of every
 // chunk strictly between (slot 0) and the FIRST run of t1 (slot 0).
@@ -358,7 +341,7 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
     load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
     for (u32 t = t0 + 1; t <= t1; t++) {
         load_xyzz<F>(q, pw + (u64)t * 2 * PW);
-        xyzz_add(acc, q); // inlined for every field: k_fixup is throughput-relevant
+        xyzz_add(acc, q);
     }
     store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
 }
@@ -380,14 +363,14 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
         xyzz_set_identity(acc);
         for (u32 c = t0 + t; c <= t1; c += 256) {
             load_xyzz<F>(q, pw + ((u64)c * 2 + (c == t0 ? 1 : 0)) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
         store_xyzz<F>(lds + t * PW, acc);
         __syncthreads();
         for (unsigned s = 128; s > 0; s >>= 1) {
             if (t < s) {
                 load_xyzz<F>(q, lds + (t + s) * PW);
-                cold_add(acc, q);
+                xyzz_add(acc, q);
                 store_xyzz<F>(lds + t * PW, acc);
             }
             __syncthreads();
@@ -422,7 +405,7 @@ __global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ b
         u32 b = g * group + j;
         if (b < NB) {
             load_xyzz<F>(q, bw + (u64)b * PW);
-            xyzz_add(run, q); // inlined for every field: k_reduce_groups does two additions per bucket
+            xyzz_add(run, q);
         }
         xyzz_add(sum, run);
     }
@@ -444,7 +427,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
         const u32 *src = gT + (u64)w * groups * PW;
         for (unsigned g = blk * 256 + t; g < groups; g += nblk * 256) {
             load_xyzz<F>(q, src + (u64)g * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
     } else {
         const unsigned j = slot - 1;
@@ -454,7 +437,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
             const unsigned g = ((i & ~low) << 1) | (1u << j) | (i & low);
             if (g >= groups) break; // g grows with i
             load_xyzz<F>(q, src + (u64)g * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
     }
     store_xyzz<F>(lds + t * PW, acc);
@@ -462,7 +445,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -481,14 +464,14 @@ __global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u
     xyzz_set_identity(acc);
     for (unsigned b = t; b < nblk; b += 64) {
         load_xyzz<F>(q, in + (((u64)w * slots + slot) * nblk + b) * PW);
-        cold_add(acc, q);
+        xyzz_add(acc, q);
     }
     store_xyzz<F>(lds + t * PW, acc);
     __syncthreads();
     for (unsigned s = 32; s > 0; s >>= 1) {
         if (t < s && t + s < nblk) { // partials beyond nblk are the identity
             load_xyzz<F>(q, lds + (t + s) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -522,21 +505,21 @@ __global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS,
     if (x < rows) {
         for (unsigned lo = t; lo < cols; lo += 256) {
             load_xyzz<F>(q, gS + ((u64)x * cols + lo) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
         dst = outR + (u64)x * PW;
     } else if (x < rows + cols) {
         const unsigned lo = x - rows;
         for (unsigned hi = t; hi < rows; hi += 256) {
             load_xyzz<F>(q, gS + ((u64)hi * cols + lo) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
         dst = outC + (u64)lo * PW;
     } else {
         const unsigned hi = x - rows - cols;
         for (unsigned lo = t; lo < cols; lo += 256) {
             load_xyzz<F>(q, gT + ((u64)hi * cols + lo) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
         dst = outT + (u64)hi * PW;
     }
@@ -545,7 +528,7 @@ __global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS,
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -569,7 +552,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
     if (slot == 0) {
         for (unsigned i = t; i < rows; i += 256) {
             load_xyzz<F>(q, inT + (u64)i * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
         }
     } else {
         const bool row_slot = slot <= a;
@@ -580,7 +563,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
         for (unsigned i = t; i < count; i += 256)
             if ((i >> j) & 1u) {
                 load_xyzz<F>(q, src + (u64)i * PW);
-                cold_add(acc, q);
+                xyzz_add(acc, q);
             }
     }
     store_xyzz<F>(lds + t * PW, acc);
@@ -588,7 +571,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -618,7 +601,7 @@ __global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32
     for (unsigned s = 32; s > 0; s >>= 1) {
         if (t < s && t + s < slots) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            cold_add(acc, q);
+            xyzz_add(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
