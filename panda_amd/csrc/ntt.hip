@@ -131,12 +131,18 @@ typedef Planes<TILE> TilePlanes;
 typedef Planes<128> TwiddlePlanes;
 
 // Rounds RND..DEG-1 of the radix-2^DEG sub-transform; BC = bound (units of p) of every element in LDS.
+// A butterfly stores s = a + b (< 2 BC p) and d = (a - b + (BC+1) p) * w (< 2p out of the product; un-multiplied, < (2 BC + 1) p,
+// in the last round).  The product needs (2 BC + 1) < 0.9 R/p at every round; when the NEXT round would break that, this round
+// brings its sum below p with the multiply-free fe_reduce_small before storing it -- one reduction per butterfly, on the sum only
+// (the difference is a fresh product), once every five or so rounds.
 template <class Fr, int DEG, int RND, int BC>
 struct Rounds {
     static constexpr long long LIM = Fr::HEADROOM * 9 / 10;
-    static constexpr bool REDUCE = (2 * BC + 1) >= LIM; // (a - b + (BC+1) p) * twiddle must stay below 0.9 R p
-    static constexpr int B0 = REDUCE ? 1 : BC;
-    static constexpr int FINAL = Rounds<Fr, DEG, RND + 1, 2 * B0 + 1>::FINAL;
+    static_assert(2 * BC + 1 < LIM, "(a - b + (BC+1) p) * twiddle must stay below 0.9 R p");
+    static constexpr bool LAST = RND == DEG - 1;
+    static constexpr bool REDUCE_SUM = !LAST && (2 * (2 * BC) + 1) >= LIM;
+    static constexpr int NEXT = LAST ? 2 * BC + 1 : (REDUCE_SUM ? 2 : 2 * BC);
+    static constexpr int FINAL = Rounds<Fr, DEG, RND + 1, NEXT>::FINAL;
     __device__ __forceinline__ static void run(const TilePlanes &u, const TwiddlePlanes &pq, unsigned blk_base, unsigned t)
     {
         constexpr unsigned R = 1u << DEG;
@@ -146,25 +152,25 @@ struct Rounds {
         Fe<Fr> a, b, s, d;
         u.load(a, blk_base + i0);
         u.load(b, blk_base + i1);
-        if (REDUCE) {
-            fe_reduce_small(a);
-            fe_reduce_small(b);
-        }
-        fe_add(s, a, b);
-        if (RND == DEG - 1) { // last round: every twiddle is 1
-            fe_sub<Fr, B0>(d, a, b);
+        if (REDUCE_SUM) {
+            fe_add_nr(s, a, b); // limbs < 2^31: fe_reduce_small carries first
+            fe_reduce_small(s);
+        } else
+            fe_add(s, a, b);
+        if (LAST) { // last round: every twiddle is 1
+            fe_sub<Fr, BC>(d, a, b);
         } else {
             // every lane multiplies (w^0 = 1 for di == 0: no lane of a wave could skip the product anyway), so the
             // difference can go into the product un-normalised
             Fe<Fr> w, raw;
-            fe_sub_raw<Fr, B0>(raw, a, b);
+            fe_sub_raw<Fr, BC>(raw, a, b);
             pq.load(w, di << RND);
             fe_mul(d, raw, w);
         }
         u.store(s, blk_base + i0);
         u.store(d, blk_base + i1);
         __syncthreads();
-        Rounds<Fr, DEG, RND + 1, 2 * B0 + 1>::run(u, pq, blk_base, t);
+        Rounds<Fr, DEG, RND + 1, NEXT>::run(u, pq, blk_base, t);
     }
 };
 template <class Fr, int DEG, int BC>
