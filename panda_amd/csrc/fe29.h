@@ -554,7 +554,7 @@ PANDA_HD void fe_reduce_once(Fe<F> &a)
 // The quotient is estimated from the top limb with a 2^-52 fixed-point reciprocal of (top limb of p) + 1,
 // which never overshoots and undershoots by at most one; needs a field whose p has a wide top limb.
 template <class F>
-PANDA_HD void fe_reduce_small(Fe<F> &a)
+PANDA_HD void fe_reduce_small_2p(Fe<F> &a) // the same down to [0, 2p), tight: enough wherever another reduction follows
 {
     constexpr int N = F::N;
     static_assert(F::P[N - 1] >= (1u << 16), "fe_reduce_small: top limb of p too narrow for the quotient estimate");
@@ -568,6 +568,12 @@ PANDA_HD void fe_reduce_small(Fe<F> &a)
         a.l[i] = (i < N - 1) ? ((u32)t & LIMB_MASK) : (u32)t;
         carry = t >> LIMB_BITS;
     }
+}
+
+template <class F>
+PANDA_HD void fe_reduce_small(Fe<F> &a)
+{
+    fe_reduce_small_2p(a);
     fe_reduce_once(a);
 }
 

@@ -154,7 +154,7 @@ struct Rounds {
         u.load(b, blk_base + i1);
         if (REDUCE_SUM) {
             fe_add_nr(s, a, b); // limbs < 2^31: fe_reduce_small carries first
-            fe_reduce_small(s);
+            fe_reduce_small_2p(s); // < 2p, like the products next to it
         } else
             fe_add(s, a, b);
         if (LAST) { // last round: every twiddle is 1
@@ -191,6 +191,7 @@ struct PassArgs {
     unsigned force_tw;    // multiply by ta[0] even when m == 0 (ta carries the n^-1 factor)
     unsigned tile_elems;  // min(TILE, n)
     unsigned strided_out; // write output i of sub-transform blk to blk + i*S (the input's own layout)
+    unsigned canonical;   // reduce the outputs to [0, p): the last pass of a transform; earlier passes stop at [0, 2p)
 };
 
 template <class Fr, int DEG>
@@ -267,7 +268,8 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
         }
         Fe<Fr> v;
         u.load(v, b * R + bitrev(i, DEG));
-        fe_reduce_small(v);
+        fe_reduce_small_2p(v);
+        if (A.canonical) fe_reduce_once(v); // between passes < 2p is enough: it fits the 32 bytes and the next pass's bounds
         store_elem(A.y + dst_index * 8, v);
     }
 }
@@ -431,6 +433,7 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
         a.la = log_p == 0 ? 16 : std::min(16u, mbits);
         a.force_tw = (scale && last) ? 1 : 0;
         a.strided_out = 0;
+        a.canonical = last ? 1 : 0;
         Fe<Fr> base;
         if (build) {
             fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
@@ -608,6 +611,7 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
         a.force_tw = 0;
         a.tile_elems = (unsigned)std::min<u64>(TILE, m);
         a.strided_out = 1;
+        a.canonical = 1;
         launch_pass<Fr>(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
         PANDA_TRY(hipGetLastError());
         out_in_scratch = 1;
