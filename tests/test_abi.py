@@ -101,3 +101,23 @@ def test_combine_partials(cid):
 def test_gpu_manager_helpers():
     assert pgm.log_2(1) == 0 and pgm.log_2(1024) == 10 and pgm.log_2(1500) == 10  # gpu_manager/common.rs:5-15
     assert pgm.FIELD_ELEMENT_LEN == 32
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/panda_interface.h is a C header (the reference's is consumed by bindgen-style Rust declarations): it compiles as
+    C11 with -Wall -Wextra -Werror, and a C translation unit that names every declared function links against the library."""
+    import re
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "panda_interface.h")).read()
+    names = sorted(set(re.findall(r"\b(panda_[a-z0-9_]+)\s*\(", header)) - {"panda_error", "panda_stream", "panda_event", "panda_mem_pool"})
+    assert set(names) == set(ffi.ALL_SYMBOLS)
+    src = tmp_path / "abi.c"
+    src.write_text('#include "panda_interface.h"\n#include <stdio.h>\nint main(void) {\n    const void *fns[] = {' +
+                   ", ".join(f"(const void *){n}" for n in names) + "};\n    size_t n = sizeof(fns) / sizeof(fns[0]), i, ok = 0;\n"
+                   "    for (i = 0; i < n; i++) ok += fns[i] != 0;\n    printf(\"%zu\\n\", ok);\n    return ok == n ? 0 : 1;\n}\n")
+    libdir = os.path.dirname(ffi.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir,
+                    "-lpanda-cuda", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    assert int(out) == len(names)
