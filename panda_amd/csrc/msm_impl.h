@@ -1,5 +1,5 @@
 // msm_impl.h -- Pippenger multi-scalar multiplication for gfx950: kernels and the per-curve driver templates.
-// Instantiated once per curve (msm_bn254.hip, msm_bls377.hip) so that the two heavy translation units build in parallel;
+// Instantiated once per curve (msm_bn254.hip, msm_bls377.hip, msm_bls381.hip) so that the heavy translation units build in parallel;
 // msm.hip holds the curve-independent host side (arena, cached-bases registry, policies, C ABI).
 //
 // Drop-in for the reference's GPU path behind panda_msm_execute_bn254
@@ -12,22 +12,22 @@
 //   one thread per bucket walks its list (:373-409)    flat chunks of K sorted entries per thread: every thread does
 //     -> collapses on skewed scalars                     exactly K mixed adds whatever the bucket sizes; bucket pieces
 //                                                        cut by a chunk boundary are merged by a fix-up kernel
-//   each bucket weighted by c doublings + adds         segmented running sums (2 adds per bucket) + one short
-//     (:411-420, ~240 mulmods per bucket)                double-and-add per 4 buckets + tree reduction
+//   each bucket weighted by c doublings + adds         segmented running sums (2 adds per bucket), the weighted sum of the
+//     (:411-420, ~240 mulmods per bucket)                group sums bit by bit with plain tree sums (no scalar multiplications)
 //   Jacobian madd 7M+4S on 8x32-bit PTX carry chains   XYZZ madd 8M+2S on 9x29-bit limbs / v_mad_u64_u32 (fe29.h)
 //   9 cudaDeviceSynchronize per call (:611-755)        one stream, one synchronisation before the host Horner
 //   scratch cudaMallocAsync'd and freed per call       per-thread arena kept between calls
 //
 // Pipeline (all on cfg.stream):
-//   k_convert_bases   wire affine -> internal Montgomery radix, 64 B/point (96 B BLS12-377)
-//   k_digits          scalar -> canonical -> W signed c-bit digits (u16 codes, window-major)
-//   k_part_hist/scan/scatter  level 1 of the sort: (id, sign, lo bits) words into 2^hi partitions, LDS histograms and cursors
-//   k_bucket_sort     level 2: one workgroup per partition ranks the lo bits in LDS -> bucket offsets + point-id lists
+//   k_convert_bases   wire affine -> internal Montgomery radix, 64 B/point (96 B for the BLS curves); skipped for registered bases
+//   msm_sort.hip      scalars -> signed window digits -> per-bucket lists of base indices (two or three LDS-staged sort levels)
 //   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
 //   k_fixup           merge bucket pieces that straddle chunks
 //   k_reduce_groups   running sums over groups of buckets
-//   k_bit_sums/finish weighted sum of the group sums, bit by bit -> one point per window
-//   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743), output conversion
+//   k_bit_sums/k_bit_finish (several lists) or k_rowcol_sums/k_bit_sums2 (one large list), k_slot_sum
+//                     weighted sum of the group sums -> one point per list
+//   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743) -- none with precomputed
+//                     tables, whose single list already carries the 2^lo[k] factors -- and output conversion
 #pragma once
 #include <algorithm>
 #include <vector>
