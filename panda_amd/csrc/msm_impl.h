@@ -262,15 +262,6 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     u32 ahead_entry = start + 1 < end ? sw[start + 1] : 0u;
     fetch_base<F>(next_base, bases, cur_entry);
     for (u32 pos = start; pos < end; pos++) {
-        if (pos >= next) { // the run of bucket b ends here
-            const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
-            store_xyzz<F>(complete ? bw + (u64)b * PW : pw, acc);
-            xyzz_set_identity(acc);
-            do {
-                b++;
-                next = ow[b + 1];
-            } while (next <= pos);
-        }
         Fe<F> cx, cy;
         bool cinf;
         const u32 entry = cur_entry;
@@ -279,6 +270,22 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
             cur_entry = ahead_entry;
             fetch_base<F>(next_base, bases, cur_entry);
             if (pos + 2 < end) ahead_entry = sw[pos + 2];
+        }
+        if (pos >= next) { // the run of bucket b ends here; this entry opens the next run, so it simply becomes the accumulator
+            const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
+            store_xyzz<F>(complete ? bw + (u64)b * PW : pw, acc);
+            do {
+                b++;
+                next = ow[b + 1];
+            } while (next <= pos);
+            if (cinf)
+                xyzz_set_identity(acc);
+            else {
+                Fe<F> ty;
+                fe_norm(ty, cy);
+                xyzz_from_affine(acc, cx, ty);
+            }
+            continue;
         }
         if (cinf) continue;
         if (xyzz_is_identity(acc)) {
