@@ -155,10 +155,14 @@ struct Rounds {
         if (REDUCE_SUM) {
             fe_add_nr(s, a, b); // limbs < 2^31: fe_reduce_small carries first
             fe_reduce_small_2p(s); // < 2p, like the products next to it
-        } else
+        } else if (LAST)
+            fe_add_nr(s, a, b); // the read-out below carries before it reduces: no normalisation here
+        else
             fe_add(s, a, b);
-        if (LAST) { // last round: every twiddle is 1
-            fe_sub<Fr, BC>(d, a, b);
+        if (LAST) { // last round: every twiddle is 1; limbs < 2^32 are fine for the read-out
+            constexpr int K = BC + SubMargin<Fr>::value;
+#pragma unroll
+            for (int i = 0; i < NL; i++) d.l[i] = a.l[i] + Fr::KP[K][i] - b.l[i];
         } else {
             // every lane multiplies (w^0 = 1 for di == 0: no lane of a wave could skip the product anyway), so the
             // difference can go into the product un-normalised
