@@ -11,9 +11,19 @@ RCCL plus the G - 1 point additions (weak scaling: per-GPU work is fixed).  Rank
   value      whole-job MSM points/s = N * 2^24 * K / wall (max over ranks, barrier + synchronize on both sides)
   roofline   the dominant kernel (k_accumulate): algorithmic bytes per launch (96 B/point) / its
              average duration, measured with HIP events on the launch stream inside the timed region
+  roofline_issue  the same kernel against the limit that actually binds it: v_mad_u64_u32 lane-operations per second
+             over the measured peak of that instruction (profiles/r01_ubench_int_rates.txt)
   cpu_baseline  the CPU oracle (port of the reference's host-debug Pippenger, c = 16, one thread) timed on a bounded
              sample on this box's host cores; N = 1 only
-  ntt        secondary figure, outside the timed region: BN254 NTT 2^24 elements/s (forward), same box
+
+Secondary figures, each measured in the same run but outside the timed region of `value` (every BASELINE.json config
+gets a number the driver records):
+  config4_msm_2_26   BN254 MSM 2^26 in total, base ranges of 2^26 / N points per rank, partials all-gathered and combined
+                     (strong scaling: at N = 8 this is BASELINE config 4 as stated, 8 x 2^23)
+  ntt                N = 1: BN254 NTT 2^24 forward and inverse (config 3)
+  ntt_sharded        N > 1: the slab-sharded transform (step 1 -> RCCL all-to-all -> step 2), 2^24 in total (strong) and
+                     2^24 per GPU (weak)
+  config2_msm_2_20, config5_bls12_377_2_24_projective   N = 1
 """
 from __future__ import annotations
 
@@ -28,8 +38,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-BYTES_PER_POINT = 96   # 32 B scalar + 64 B affine base
+BYTES_PER_POINT = {0: 96, 1: 128, 2: 128}  # 32 B scalar + affine base
 BYTES_PER_NTT_ELEM = 64
+POINT_BYTES = {0: 64, 1: 96, 2: 96}
+RESULT_BYTES = {0: 96, 1: 144, 2: 144}
+# v_mad_u64_u32 lane-operations per second, whole chip, 8 waves per SIMD: profiles/r01_ubench_int_rates.txt ("mad_u64_u32 ... 28450.16 Gop/s")
+MAD_PEAK_PER_S = 28.45e12
+# multiply-adds of one XYZZ mixed addition on 9 x 29-bit limbs: 8 products of 162, 2 squarings of 126, one shared reduction
+# (counted in the ISA of k_accumulate<Bn254Fq>)
+MADS_PER_ADDITION_BN254 = 1467
+SEED = 0x70616E6461
 
 
 def parse():
@@ -37,15 +55,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=24, help="log2 of the points per GPU (contract: 24)")
+    ap.add_argument("--log-n", type=int, default=24, help="log2 of the points per GPU of the headline leg (contract: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 2^26-total strong-scaling leg")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config 2 / config 5 legs (N = 1)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the contract) or gloo (rehearsal of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-register", action="store_true", help="do not register the cached bases (plain drop-in call path)")
     ap.add_argument("--no-tables", action="store_true", help="register the cached bases without precomputed window tables")
-    ap.add_argument("--no-compare", action="store_true", help="skip the extra without-tables measurement (profiling runs)")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra without-tables and PCIe measurements (profiling runs)")
+    ap.add_argument("--config4-total-log-n", type=int, default=26)
     return ap.parse_args()
 
 
@@ -71,115 +92,177 @@ def cpu_baseline(sample_log_n: int) -> dict:
     return out
 
 
+class Ctx:
+    """What every leg needs: the library, this rank's device and stream, the process group."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        from panda_amd import gpu_ffi as ffi
+        from panda_amd import multi_gpu
+
+        self.torch, self.dist, self.ffi, self.multi_gpu, self.args = torch, dist, ffi, multi_gpu, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = 0 if args.all_on_device0 else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.nccl = args.dist_backend == "nccl"
+        if self.world > 1:
+            if self.nccl:
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(args.dist_backend)
+        self.lib = ffi.load()
+        ffi.check(self.lib.panda_set_device(local_rank), "SetDeviceError")
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.pstream = ffi.PandaStream(self.stream.cuda_stream)
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.lib.panda_stream_sync(self.pstream)
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.world == 1:
+            return dt
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.nccl else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, warmup: int, steps: int) -> float:
+        """The contract's protocol: W untimed steps, barrier + synchronize, K steps, barrier + synchronize, max over ranks."""
+        for _ in range(warmup):
+            step(False)
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+class MsmProblem:
+    """One rank's share of an MSM: 2^log_n synthetic points and scalars generated in HBM (range [first, first + n) of the
+    seeded stream), optionally registered / tabled, plus the exchange + combine step for N > 1."""
+
+    def __init__(self, ctx: Ctx, curve: int, log_n: int, seed: int, coord: int, first: int = 0, register: bool = True, tables: bool = True):
+        torch, ffi, lib = ctx.torch, ctx.ffi, ctx.lib
+        self.ctx, self.curve, self.log_n, self.n = ctx, curve, log_n, 1 << log_n
+        n = self.n
+        self.bases = torch.empty(n * POINT_BYTES[curve], dtype=torch.uint8, device=ctx.dev)
+        self.scalars = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
+        self.result = torch.zeros(RESULT_BYTES[curve], dtype=torch.uint8, device=ctx.dev)
+        ffi.check(lib.panda_gen_bases(curve, seed, first, n, self.bases.data_ptr(), ctx.pstream), "gen_bases")
+        ffi.check(lib.panda_gen_scalars(curve, seed ^ 0xFFFF, first, n, self.scalars.data_ptr(), ctx.pstream), "gen_scalars")
+        self.fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[curve]
+        self.cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ctx.pstream, self.bases.data_ptr(), self.scalars.data_ptr(), self.result.data_ptr(), log_n, coord)
+        self.coord = coord
+        self.tables, self.wbits, self.held, self.t_reg = 0, 0, 0, 0.0
+        self.mode = "resident, plain pointer"
+        self.registered = False
+        if register:
+            self.register(tables)
+        self.total = None
+
+    def register(self, tables: bool):
+        """"cached bases" (BASELINE config): the base set stays on the device across MSMs and is registered once, so the
+        library keeps its radix-converted copy -- and, with tables, the window tables 2^lo[k]*P built from it -- instead of
+        re-deriving them in every call.  Built before any timed region; depends on the bases only."""
+        ctx, lib, ffi = self.ctx, self.ctx.lib, self.ctx.ffi
+        if self.registered:
+            ffi.check(lib.panda_msm_unregister_bases(self.bases.data_ptr()), "unregister_bases")
+        t = time.perf_counter()
+        if tables and lib.panda_msm_precompute_bases(self.curve, self.bases.data_ptr(), self.log_n, 0, ctx.pstream) != 0:
+            tables = False  # e.g. not enough free HBM for the tables: fall back to the converted copy alone
+        if not tables:
+            ffi.check(lib.panda_msm_register_bases(self.curve, self.bases.data_ptr(), self.log_n, ctx.pstream), "register_bases")
+        self.t_reg = time.perf_counter() - t
+        tb, wb, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
+        ffi.check(lib.panda_msm_registered_info(self.bases.data_ptr(), C.byref(tb), C.byref(wb), C.byref(held)), "registered_info")
+        self.tables, self.wbits, self.held = tb.value, wb.value, held.value
+        self.registered = True
+        if self.tables > 1:
+            self.mode = (f"cached: resident, registered with {self.tables} precomputed window tables of {self.wbits}-bit windows "
+                         f"(panda_msm_precompute_bases: {self.held / 2**30:.1f} GiB, built once in {self.t_reg:.2f} s, outside the timed region)")
+        else:
+            self.mode = "cached: resident and registered (panda_msm_register_bases)"
+
+    def execute(self):
+        self.ctx.ffi.check(self.fn(self.cfg), "SchedulingErr")
+
+    def exchange(self):
+        """N > 1: all-gather of the result-sized partials (RCCL, device buffers) + the G - 1 point additions."""
+        ctx = self.ctx
+        if ctx.world == 1:
+            return
+        if ctx.nccl:
+            gathered = ctx.torch.empty(ctx.world * self.result.numel(), dtype=ctx.torch.uint8, device=ctx.dev)
+            ctx.dist.all_gather_into_tensor(gathered, self.result)
+            partials = gathered.cpu().numpy().reshape(ctx.world, -1)
+        else:
+            partials = ctx.multi_gpu.allgather_partials(self.result.cpu().numpy())
+        self.total = ctx.multi_gpu.combine_partials(partials, self.curve, self.coord)
+
+    def phases(self):
+        ph = (C.c_float * 8)()
+        self.ctx.lib.panda_msm_last_phase_ms(ph)
+        return list(ph)
+
+    def release(self):
+        if self.registered:
+            self.ctx.lib.panda_msm_unregister_bases(self.bases.data_ptr())
+            self.registered = False
+        self.bases = self.scalars = self.result = None
+        self.ctx.torch.cuda.empty_cache()
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
-
-    import torch
-    import torch.distributed as dist
-
-    from panda_amd import gpu_ffi as ffi
-    from panda_amd import multi_gpu
-
-    if args.all_on_device0:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend)
-    lib = ffi.load()
-    ffi.check(lib.panda_set_device(local_rank), "SetDeviceError")
+    ctx = Ctx(args)
+    lib, rank = ctx.lib, ctx.rank
 
     log_n = args.log_n
     n = 1 << log_n
-    stream = torch.cuda.Stream(device=dev)
-    pstream = ffi.PandaStream(stream.cuda_stream)
-    bases = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
-    result = torch.zeros(96, dtype=torch.uint8, device=dev)
-    first = rank * n  # this rank's base range of the virtual N * 2^log_n problem
-    ffi.check(lib.panda_gen_bases(0, 0x70616E6461, first, n, bases.data_ptr(), pstream), "gen_bases")
-    ffi.check(lib.panda_gen_scalars(0, 0x70616E6461 ^ 0xFFFF, first, n, scalars.data_ptr(), pstream), "gen_scalars")
-    bases_mode = "resident, plain pointer"
-    if not args.no_register:
-        # "cached bases" (BASELINE config): the base set stays on the device across MSMs and is registered once, so the
-        # library keeps its radix-converted copy -- and, unless --no-tables, the window tables 2^lo[k]*P built from it --
-        # instead of re-deriving them in every call.  Built before the timed region; depends on the bases only.
-        t_reg = time.perf_counter()
-        use_tables = not args.no_tables
-        if use_tables and lib.panda_msm_precompute_bases(0, bases.data_ptr(), log_n, 0, pstream) != 0:
-            use_tables = False  # e.g. not enough free HBM for the tables: fall back to the converted copy alone
-        if not use_tables:
-            ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
-        t_reg = time.perf_counter() - t_reg
-        tables, wbits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
-        ffi.check(lib.panda_msm_registered_info(bases.data_ptr(), C.byref(tables), C.byref(wbits), C.byref(held)), "registered_info")
-        if not use_tables:
-            bases_mode = "cached: resident and registered (panda_msm_register_bases)"
-        else:
-            bases_mode = (f"cached: resident, registered with {tables.value} precomputed window tables of {wbits.value}-bit windows "
-                          f"(panda_msm_precompute_bases: {held.value / 2**30:.1f} GiB, built once in {t_reg:.2f} s, outside the timed region)")
-    cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), pstream, bases.data_ptr(), scalars.data_ptr(), result.data_ptr(), log_n, ffi.JACOBIAN)
-
-    phase = (C.c_float * 8)()
+    prob = MsmProblem(ctx, 0, log_n, SEED, ctx.ffi.JACOBIAN, first=rank * n, register=not args.no_register, tables=not args.no_tables)
     acc_ms = []
 
     def step(timed: bool):
-        ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
+        prob.execute()
         if timed:
-            lib.panda_msm_last_phase_ms(phase)
-            acc_ms.append(list(phase))
-        if world > 1:
-            if args.dist_backend == "nccl":  # 96 B per rank over RCCL, device buffers
-                gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(gathered, result)
-                partials = gathered.cpu().numpy().reshape(world, 96)
-            else:
-                partials = multi_gpu.allgather_partials(result.cpu().numpy())
-            step.total = multi_gpu.combine_partials(partials)
+            acc_ms.append(prob.phases())
+        prob.exchange()
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        lib.panda_stream_sync(pstream)
+    dt = ctx.timed(step, args.warmup, args.steps)
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    out = None
     if rank == 0:
         names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
         mean = [sum(r[i] for r in acc_ms) / len(acc_ms) for i in range(8)]
         acc_kernel_ms = mean[3]
-        achieved = BYTES_PER_POINT * n / (acc_kernel_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = BYTES_PER_POINT[0] * n / (acc_kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 if tr.get("log_n") == log_n:
                     traffic = tr.get("k_accumulate_hbm_bytes_per_launch")
+                    traffic_src = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, {tr.get('source')}"
             except Exception:
                 traffic = None
+        windows = prob.tables if prob.tables > 1 else None
+        total_log = log_n + (world.bit_length() - 1)
+        workload = f"BN254 MSM 2^{log_n} points per GPU, Jacobian output, bases and scalars resident in HBM"
+        if world > 1:
+            workload += f" ({world} base ranges, 2^{total_log} points in total)" if world & (world - 1) == 0 else f" ({world} base ranges)"
         out = {
             "metric": "MSM points/s (BN254, 2^24)",
             "value": world * n * args.steps / dt,
@@ -193,48 +276,110 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"BN254 MSM 2^{log_n} points per GPU, Jacobian output, bases and scalars resident in HBM",
-                       "curve": "bn254", "log_points_per_gpu": log_n,
-                       "bases": bases_mode, "sharding": f"base-range x{world}" if world > 1 else "none",
-                       "exchange": f"all-gather of 96 B partials ({'RCCL' if args.dist_backend == 'nccl' else args.dist_backend}) + host point additions" if world > 1 else "none"},
+            "config": {"workload": workload, "curve": "bn254", "log_points_per_gpu": log_n,
+                       "bases": prob.mode, "sharding": f"base-range x{world}" if world > 1 else "none",
+                       "exchange": f"all-gather of 96 B partials ({'RCCL' if ctx.nccl else args.dist_backend}) + host point additions" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * n, "kernel_ms": acc_kernel_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": BYTES_PER_POINT[0] * n, "kernel_ms": acc_kernel_ms},
             "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
         }
+        if windows:
+            # what actually bounds k_accumulate: every sorted entry is one XYZZ mixed addition; a digit is zero
+            # with probability 2^-c, so W * n additions per launch to within 1e-6 for random scalars
+            additions = windows * n
+            mads = additions * MADS_PER_ADDITION_BN254 / (acc_kernel_ms * 1e-3)
+            out["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "kernel": "k_accumulate", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
+                                     "unit": "T mad lane-ops/s", "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions,
+                                     "mads_per_addition": MADS_PER_ADDITION_BN254, "kernel_ms": acc_kernel_ms,
+                                     "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s"}
+
+    def leg(name, fn):
+        """Secondary figures never take the contract line down with them: a failure is reported in place of the number."""
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            res = {"error": repr(e)[:300]}
+        if rank == 0 and res is not None:
+            out[name] = res
+
+    if world == 1 and not args.no_compare:
+        leg("pcie_inclusive", lambda: pcie_inclusive(ctx, prob))
+        if prob.tables > 1:
+            leg("without_tables", lambda: without_tables(ctx, prob, max(2, args.steps // 2)))
+    prob.release()
+
+    if not args.no_config4 and world & (world - 1) == 0 and world <= 64:
+        leg("config4_msm_2_26", lambda: config4(ctx, args.config4_total_log_n))
+    if not args.no_ntt:
         if world == 1:
-            out["pcie_inclusive"] = pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n)
-            if not args.no_register and not args.no_tables and not args.no_compare and tables.value > 1:
-                out["without_tables"] = without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, max(2, args.steps // 2))
-        if not args.no_ntt:
-            out["ntt"] = ntt_figure(lib, ffi, torch, dev, pstream)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n)
+            leg("ntt", lambda: ntt_figure(ctx))
+        elif world & (world - 1) == 0:
+            leg("ntt_sharded", lambda: ntt_sharded_figure(ctx))
+    if world == 1 and not args.no_extra_configs:
+        leg("config2_msm_2_20", lambda: small_config(ctx, 0, 20, ctx.ffi.JACOBIAN, 20, "BN254 MSM 2^20, Jacobian output, cached bases (BASELINE config 2)"))
+        leg("config5_bls12_377_2_24_projective",
+            lambda: small_config(ctx, 1, 24, ctx.ffi.PROJECTIVE, 5, "BLS12-377 MSM 2^24 + Projective-output conversion (BASELINE config 5)"))
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        leg("cpu_baseline", lambda: cpu_baseline(args.cpu_sample_log_n))
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
-def without_tables(lib, ffi, bases, log_n, pstream, cfg, fence, steps) -> dict:
+def config4(ctx: Ctx, total_log_n: int) -> dict:
+    """BASELINE config 4: BN254 MSM 2^26, sharded by base range over the ranks, partial sums all-gathered and combined.
+    Strong scaling: the total is fixed, rank r owns points [r 2^26/N, (r+1) 2^26/N) of one seeded stream."""
+    g = ctx.world.bit_length() - 1
+    log_per = total_log_n - g
+    per = 1 << log_per
+    prob = MsmProblem(ctx, 0, log_per, SEED ^ 0xC4, ctx.ffi.JACOBIAN, first=ctx.rank * per, register=True, tables=True)
+    steps = 3
+
+    def step(_timed):
+        prob.execute()
+        prob.exchange()
+
+    dt = ctx.timed(step, 1, steps)
+    ph = prob.phases()
+    res = {"metric": f"MSM points/s (BN254, 2^{total_log_n} in total)", "value": (1 << total_log_n) * steps / dt, "unit": "points/s",
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": ctx.world, "scaling": "strong", "log_points_per_gpu": log_per,
+           "workload": f"BN254 MSM 2^{total_log_n}, {ctx.world} base range(s) of 2^{log_per} points, all-gather of 96 B partials + combine",
+           "bases": prob.mode, "k_accumulate_ms_rank0": ph[3], "device_ms_rank0": ph[7]}
+    prob.release()
+    return res
+
+
+def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what: str) -> dict:
+    """One of BASELINE.json's single-GPU configurations, with and without precomputed tables."""
+    prob = MsmProblem(ctx, curve, log_n, SEED ^ (0x100 + curve * 16 + log_n), coord, register=True, tables=True)
+    res = {"workload": what, "unit": "points/s", "steps": steps}
+    for label in ("with_tables", "registered_only"):
+        if label == "registered_only":
+            prob.register(False)
+        dt = ctx.timed(lambda _t: prob.execute(), 2, steps) / steps
+        ph = prob.phases()
+        res[label] = {"value": prob.n / dt, "ms_per_step": dt * 1e3, "bases": prob.mode, "k_accumulate_ms": ph[3], "device_ms": ph[7],
+                      "roofline_frac_hbm": BYTES_PER_POINT[curve] * prob.n / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res["value"] = res["with_tables"]["value"]
+    prob.release()
+    return res
+
+
+def without_tables(ctx: Ctx, prob: MsmProblem, steps: int) -> dict:
     """The same call with the bases registered but no window tables (run after the timed region, for comparison)."""
-    ffi.check(lib.panda_msm_unregister_bases(bases.data_ptr()), "unregister_bases")
-    ffi.check(lib.panda_msm_register_bases(0, bases.data_ptr(), log_n, pstream), "register_bases")
-    ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ffi.check(lib.panda_msm_execute_bn254(cfg), "SchedulingErr")
-    fence()
-    dt = (time.perf_counter() - t0) / steps
-    phase = (C.c_float * 8)()
-    lib.panda_msm_last_phase_ms(phase)
-    return {"ms_per_step": dt * 1e3, "value": (1 << log_n) / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": phase[3]}
+    prob.register(False)
+    dt = ctx.timed(lambda _t: prob.execute(), 1, steps) / steps
+    return {"ms_per_step": dt * 1e3, "value": prob.n / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": prob.phases()[3]}
 
 
-def pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n) -> dict:
+def pcie_inclusive(ctx: Ctx, prob: MsmProblem) -> dict:
     """Non-cached-scalars variant (unit.rs:103-188): scalars start in pinned host memory and cross PCIe inside the
     measurement.  Informative only -- never the headline `value` (inputs resident in HBM)."""
+    torch, lib, ffi, pstream, cfg, n = ctx.torch, ctx.lib, ctx.ffi, ctx.pstream, prob.cfg, prob.n
+    scalars = prob.scalars
     host = torch.empty(n * 32, dtype=torch.uint8).pin_memory()
     host.copy_(scalars.cpu())
     best = 1e9
@@ -246,7 +391,7 @@ def pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n) -> dict:
     out = {"value": n / best, "unit": "points/s", "ms": best * 1e3, "note": "scalars H2D (pinned, 32 B/point) + MSM, bases cached"}
     # the same with the caller-side pipeline the reference's three streams are meant for (wrapper.rs:12-14): the upload of
     # batch k+1 runs on an h2d stream while batch k executes; an event orders each execute after its own upload
-    copy_stream = torch.cuda.Stream(device=dev)
+    copy_stream = torch.cuda.Stream(device=ctx.dev)
     pcopy = ffi.PandaStream(copy_stream.cuda_stream)
     bufs = [scalars, torch.empty_like(scalars)]
     events = []
@@ -274,16 +419,17 @@ def pcie_inclusive(lib, ffi, torch, dev, pstream, cfg, scalars, n) -> dict:
     return out
 
 
-def ntt_figure(lib, ffi, torch, dev, pstream, log_n: int = 24, reps: int = 5) -> dict:
-    """BN254 NTT 2^24 forward, device-resident, median of `reps` (secondary headline figure)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
+    """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident, median of `reps`."""
+    torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
     n = 1 << log_n
-    a = torch.empty(n * 32, dtype=torch.uint8, device=dev)
-    b = torch.empty(n * 32, dtype=torch.uint8, device=dev)
-    ffi.check(lib.panda_gen_scalars(0, 0x4E5454, 0, n, a.data_ptr(), pstream), "gen")
-    omega = _root_of_unity_host(lib, ffi, log_n)
+    a = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
+    b = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
+    ffi.check(lib.panda_gen_scalars(0, 0x4E5454, 0, n, a.data_ptr(), ctx.pstream), "gen")
+    omega = _root_of_unity_host(log_n)
     flag = C.c_uint(0)
-    cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
+    cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), ctx.pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
+
     def timed(fn):
         ts = []
         for r in range(reps + 1):
@@ -298,12 +444,48 @@ def ntt_figure(lib, ffi, torch, dev, pstream, log_n: int = 24, reps: int = 5) ->
     inv = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
     return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3,
-            "inverse_ms": inv * 1e3, "forward_plus_inverse_elements_per_s": n / (fwd + inv),
+            "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv, "forward_plus_inverse_ms": (fwd + inv) * 1e3,
+            "forward_plus_inverse_elements_per_s": n / (fwd + inv),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 
 
-def _root_of_unity_host(lib, ffi, log_n):
+def ntt_sharded_figure(ctx: Ctx, reps: int = 5) -> dict:
+    """N > 1: the slab-sharded forward transform, composed on the devices (multi_gpu.ntt_sharded: panda_ntt_slab_step1_bn254 ->
+    all_to_all_single over RCCL -> panda_ntt_slab_step2_bn254).  Strong: 2^24 elements in total; weak: 2^24 per GPU."""
+    torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
+    g = ctx.world.bit_length() - 1
+    res = {"exchange": f"all_to_all_single ({'RCCL, device buffers' if ctx.nccl else ctx.args.dist_backend + ', staged through the host'}), "
+                       f"each rank sends (N-1)/N of its slab", "n_gpus": ctx.world, "unit": "elements/s"}
+    for label, total_log in (("strong_2_24_total", 24), ("weak_2_24_per_gpu", min(24 + g, 28))):
+        m = (1 << total_log) >> g
+        slab = torch.empty(m * 32, dtype=torch.uint8, device=ctx.dev)
+        scratch = torch.empty_like(slab)
+        keep = torch.empty_like(slab)
+        ffi.check(lib.panda_gen_scalars(0, 0x4E5455, ctx.rank * m, m, keep.data_ptr(), ctx.pstream), "gen")
+        omega = _root_of_unity_host(total_log)
+
+        def step(_timed):
+            slab.copy_(keep)  # the transform overwrites both buffers; the refill is a device-to-device copy inside the loop
+            ctx.multi_gpu.ntt_sharded(slab, scratch, omega, total_log, stream=ctx.stream)
+
+        def refill_only(_timed):
+            slab.copy_(keep)
+
+        dt = ctx.timed(step, 2, reps) / reps
+        dt_copy = ctx.timed(refill_only, 1, reps) / reps
+        t = max(dt - dt_copy, 1e-9)
+        res[label] = {"value": (1 << total_log) / t, "ms": t * 1e3, "log_n_total": total_log, "elements_per_gpu": m,
+                      "exchange_bytes_per_gpu": m * 32 * (ctx.world - 1) // ctx.world,
+                      "scaling": "strong" if label.startswith("strong") else "weak"}
+        del slab, scratch, keep
+        torch.cuda.empty_cache()
+    res["value"] = res["strong_2_24_total"]["value"]
+    res["metric"] = "NTT elements/s (BN254 Fr, 2^24 in total, slab-sharded forward)"
+    return res
+
+
+def _root_of_unity_host(log_n):
     """omega of order 2^log_n in wire form: 7^((r-1)/2^28) squared down (bn254/paramter.cuh:241-258), computed with
     Python integers -- no oracle involved."""
     import numpy as np

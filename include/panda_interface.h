@@ -217,8 +217,8 @@ panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg);
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
 panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
 
-/* Element-wise diagnostics used by the parity tests: field id 0..3 = BN254 Fq, BN254 Fr, BLS12-377 Fq, BLS12-377 Fr;
- * op 0..5 = add, sub, mul, sqr, to_montgomery, from_montgomery.  Device pointers. */
+/* Element-wise diagnostics used by the parity tests: field id 0..5 = BN254 Fq, BN254 Fr, BLS12-377 Fq, BLS12-377 Fr, BLS12-381 Fq, BLS12-381 Fr;
+ * op 0..6 = add, sub, mul, sqr, to_montgomery, from_montgomery, inverse (Montgomery in/out, 0 -> 0; field.cuh:925-972).  Device pointers. */
 panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);
 /* op 0 = Jacobian + affine (madd), 1 = Jacobian + Jacobian, 2 = double; Jacobian in/out */
 panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);

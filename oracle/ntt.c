@@ -12,6 +12,8 @@
  *   po_ntt_passes  the reference's pass structure: radix-2^deg Stockham passes, deg = min(8,
  *                  remaining), src/dst ping-pong, flag = passes & 1 (fft.cu:177,193-211); the
  *                  per-pass index arithmetic follows the commented radix_fft (fft.cu:122-167)
+ *   po_ntt_eval_at one output of the same definition by Horner's rule in O(n): the check for sizes
+ *                  po_ntt would need minutes for (spot-check by direct evaluation)
  *   po_root_of_unity  BN254 Fr: generator 7, two-adicity 28 (bn254/paramter.cuh:241-258)
  */
 #include "panda_oracle.h"
@@ -206,5 +208,24 @@ int po_root_of_unity(int field_id, unsigned log_n, void *omega_mont)
     }
     for (unsigned s = log_n; s < two_adicity; s++) po_f_sqr(f, acc, acc);
     memcpy(omega_mont, acc, lc * 4);
+    return 0;
+}
+
+/* y[k] = sum_j x[j] * (omega^k)^j for ONE output index k, by Horner's rule from the top coefficient down:
+ * n multiplications and n additions, no table.  Same definition as po_dft_naive (fft.cu:103-169). */
+int po_ntt_eval_at(int field_id, void *out_, const void *in_, const void *omega, unsigned log_n, uint64_t k)
+{
+    const po_field *f = po_field_get(field_id);
+    if (!f || log_n > 30) return 1;
+    const unsigned lc = f->lc;
+    const size_t n = (size_t)1 << log_n;
+    const u32 *in = (const u32 *)in_;
+    u32 wk[LCMAX], acc[LCMAX] = {0}, t[LCMAX];
+    po_f_pow_u64(f, wk, (const u32 *)omega, k & (n - 1));
+    for (size_t j = n; j-- > 0;) {
+        po_f_mul(f, t, acc, wk);
+        po_f_add(f, acc, t, in + j * lc);
+    }
+    memcpy(out_, acc, lc * 4);
     return 0;
 }

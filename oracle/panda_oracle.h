@@ -109,6 +109,8 @@ int po_msm_mt(int curve, const void *bases, const void *scalars, uint64_t n, uns
  */
 int po_ntt(int field_id, void *out, const void *in, const void *omega, unsigned log_n);
 int po_dft_naive(int field_id, void *out, const void *in, const void *omega, unsigned log_n);
+/* one output y[k] of the same definition in O(n) (Horner) */
+int po_ntt_eval_at(int field_id, void *out, const void *in, const void *omega, unsigned log_n, uint64_t k);
 /* literal restatement of the reference's pass structure (radix-2^deg Stockham passes with ping-pong);
  * returns the `flag` the reference would write (fft.cu:211), result always copied to `out` */
 int po_ntt_passes(int field_id, void *out, const void *in, const void *omega, unsigned log_n, unsigned *flag);

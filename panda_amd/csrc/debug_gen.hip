@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) k_field_op(unsigned op, u32 *__restrict__
         if (op == 0) fe_add(z, x, y);
         else if (op == 1) fe_sub<F, 2>(z, x, y);
         else if (op == 2) fe_mul(z, x, y);
-        else fe_sqr(z, x);
+        else if (op == 3) fe_sqr(z, x);
+        else fe_inv(z, x); // a^(p-2): the inversion k_table_step and the host-side output conversion use; 0 -> 0
         fe_to_wire(wr, z);
     }
 #pragma unroll
@@ -276,7 +277,7 @@ extern "C" {
 
 panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream)
 {
-    if (op > 5 || field_id > 5) return panda_error_invalid_value;
+    if (op > 6 || field_id > 5) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     u32 *r = (u32 *)d_r;

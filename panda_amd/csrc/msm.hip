@@ -2,6 +2,8 @@
 // The kernels and the per-call driver live in msm_impl.h (instantiated per curve in msm_bn254.hip / msm_bls377.hip),
 // the digit extraction and the bucket sort in msm_sort.hip.
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -39,6 +41,12 @@ hipError_t Arena::reserve(size_t bytes)
     return hipSuccess;
 }
 
+Arena::~Arena()
+{
+    // a host thread that ends without calling panda_msm_tear_down() must not leak its scratch (several GiB at 2^24)
+    if (base) (void)hipFree(base);
+}
+
 hipError_t Arena::release()
 {
     hipError_t e = hipSuccess;
@@ -70,24 +78,60 @@ thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 // set on the device for many MSMs may register it; the radix conversion k_convert_bases would repeat on every call is
 // then done once and kept next to it -- optionally together with the window tables above.  The caller promises not to
 // modify a registered buffer until it is unregistered.
-typedef panda::MsmRegistration RegisteredBases;
+//
+// Lifetime: an entry owns its device copy and is handed out as a shared_ptr, so a call that is executing keeps the
+// tables alive even if another host thread unregisters them meanwhile; the memory goes when the last user lets go.
+// Staleness: the key is the caller's raw device address, which an allocator may hand out again.  panda_free /
+// panda_free_async drop every entry whose buffer lies in the allocation being freed, and for buffers freed behind the
+// library's back (a caching allocator such as torch's) each entry keeps REG_SAMPLES rows of the wire buffer as it was
+// at registration: every execute compares them on the device and, on a mismatch, forgets the entry and runs the call
+// again from the caller's buffer, so a recycled address can never serve another base set's tables.
+struct RegisteredBases : panda::MsmRegistration {
+    RegisteredBases() : panda::MsmRegistration{} {}
+    RegisteredBases(const RegisteredBases &) = delete;
+    RegisteredBases &operator=(const RegisteredBases &) = delete;
+    ~RegisteredBases()
+    {
+        if (converted) (void)hipFree(converted); // waits for the device: nothing can still be reading the tables
+    }
+};
+typedef std::shared_ptr<RegisteredBases> RegisteredPtr;
 std::mutex g_registry_mutex;
-std::vector<RegisteredBases> g_registry;
+std::vector<RegisteredPtr> g_registry;
+std::atomic<size_t> g_registry_count{0}; // lets panda_free skip the lock when nothing is registered
 
-bool lookup_registered(RegisteredBases &out, const void *wire, unsigned log_n, unsigned curve)
+RegisteredPtr lookup_registered(const void *wire, unsigned log_n, unsigned curve)
 {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_registry_count.load(std::memory_order_acquire) == 0 || hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     for (const auto &r : g_registry)
-        if (r.wire == wire && r.log_n == log_n && r.curve == curve && r.device == dev) {
-            out = r;
-            return true;
-        }
-    return false;
+        if (r->wire == wire && r->log_n == log_n && r->curve == curve && r->device == dev) return r;
+    return nullptr;
 }
-unsigned g_window_override = 0;
-unsigned g_reduce_group = 0;
+
+// removes the entries `pred` selects; their device memory is released after the lock is dropped, and only once no
+// executing call holds them any more
+template <class Pred>
+size_t forget_if(Pred pred)
+{
+    std::vector<RegisteredPtr> dropped;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        for (size_t i = 0; i < g_registry.size();) {
+            if (pred(*g_registry[i])) {
+                dropped.push_back(std::move(g_registry[i]));
+                g_registry.erase(g_registry.begin() + i);
+            } else
+                i++;
+        }
+        g_registry_count.store(g_registry.size(), std::memory_order_release);
+    }
+    return dropped.size();
+}
+
+std::atomic<unsigned> g_window_override{0};
+std::atomic<unsigned> g_reduce_group{0};
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
@@ -95,7 +139,8 @@ const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort
 // window width policy (replaces get_window_bits_count, msm_cuda.cuh:21-45)
 unsigned pick_window_bits(unsigned log_n)
 {
-    if (g_window_override) return std::min(std::max(g_window_override, 4u), 16u);
+    const unsigned forced = g_window_override.load(std::memory_order_relaxed);
+    if (forced) return std::min(std::max(forced, 4u), 16u);
     int c = (int)log_n - 4;
     return (unsigned)std::min(std::max(c, 4), 16);
 }
@@ -121,49 +166,81 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
     return best;
 }
 
+hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale)
+{
+    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group.load(std::memory_order_relaxed)};
+    switch (curve) {
+    case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale);
+    case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale);
+    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms, stale);
+    }
+}
+
 hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg)
 {
     if (cfg.log_scalars_count > 26 || !cfg.bases) return hipErrorInvalidValue;
-    RegisteredBases reg{};
-    const bool registered = lookup_registered(reg, cfg.bases, cfg.log_scalars_count, curve);
-    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group};
-    const RegisteredBases *r = registered ? &reg : nullptr;
-    switch (curve) {
-    case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms);
-    case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms);
-    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms);
+    const RegisteredPtr reg = lookup_registered(cfg.bases, cfg.log_scalars_count, curve); // held for the whole call
+    bool stale = false;
+    hipError_t e = msm_execute_on(curve, cfg, reg.get(), &stale);
+    if (e == hipSuccess && stale) {
+        // the buffer no longer holds the bases it held when it was registered (freed and reallocated behind our back):
+        // the entry is dropped and the call answered from the caller's buffer as it is now
+        printf("[panda-hip] registered bases at %p changed since registration: registration dropped, converting per call\n", cfg.bases);
+        const RegisteredBases *gone = reg.get();
+        forget_if([gone](const RegisteredBases &r) { return &r == gone; });
+        e = msm_execute_on(curve, cfg, nullptr, nullptr);
     }
+    return e;
 }
 
 hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
 {
     if (curve > 2 || !d_bases || log_n > 26) return hipErrorInvalidValue;
-    RegisteredBases r{};
-    if (lookup_registered(r, d_bases, log_n, curve)) {
-        if (!tabled && !r.tabled) return hipSuccess;
-        if (tabled && (r.tabled || log_n < 4)) return hipSuccess; // tables exist (or were not worth building)
+    if (const RegisteredPtr have = lookup_registered(d_bases, log_n, curve)) {
+        if (!tabled && !have->tabled) return hipSuccess;
+        if (tabled && (have->tabled || log_n < 4)) return hipSuccess; // tables exist (or were not worth building)
         return hipErrorInvalidValue; // registered differently: unregister first
     }
-    r = RegisteredBases{};
-    r.wire = d_bases;
-    r.log_n = log_n;
-    r.curve = curve;
-    r.tabled = tabled;
-    PANDA_TRY(hipGetDevice(&r.device));
+    RegisteredPtr r = std::make_shared<RegisteredBases>();
+    r->wire = d_bases;
+    r->log_n = log_n;
+    r->curve = curve;
+    r->tabled = tabled;
+    PANDA_TRY(hipGetDevice(&r->device));
     if (tabled) {
         if (window_bits && (window_bits < 4 || window_bits > 24)) return hipErrorInvalidValue;
         const unsigned c = window_bits ? window_bits : pick_tabled_window_bits(curve, log_n);
-        if (c) r.plan = panda::make_safe_window_plan(curve, c);
+        if (c) r->plan = panda::make_safe_window_plan(curve, c);
         // sizes the three-level sort has no geometry for (a handful of points) keep the converted copy only
-        if (!c || !panda::msm_sort_tabled_supported(log_n, r.plan)) r.tabled = false;
+        if (!c || !panda::msm_sort_tabled_supported(log_n, r->plan)) r->tabled = false;
     }
-    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(r, s) : (curve == 1 ? panda::msm_build_registration_bls377(r, s) : panda::msm_build_registration_bls381(r, s)));
+    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(*r, s) : (curve == 1 ? panda::msm_build_registration_bls377(*r, s) : panda::msm_build_registration_bls381(*r, s)));
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    g_registry.push_back(r);
+    g_registry.push_back(std::move(r));
+    g_registry_count.store(g_registry.size(), std::memory_order_release);
     return hipSuccess;
 }
 
 } // namespace
+
+namespace panda {
+
+// panda_free / panda_free_async: no registration may outlive the buffer it was made for
+void registry_forget_allocation(const void *ptr)
+{
+    if (!ptr || g_registry_count.load(std::memory_order_acquire) == 0) return;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void *>(ptr)) != hipSuccess || !base || !size) {
+        (void)hipGetLastError(); // not a range the runtime can describe (stream-ordered pool memory): match the address itself
+        base = const_cast<void *>(ptr);
+        size = 1;
+    }
+    const char *lo = (const char *)base, *hi = lo + size;
+    forget_if([lo, hi](const RegisteredBases &r) { return (const char *)r.wire >= lo && (const char *)r.wire < hi; });
+}
+
+} // namespace panda
 
 // ------------------------------------------------------------------------------- C ABI
 
@@ -189,10 +266,10 @@ panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, uns
 {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     for (const auto &r : g_registry)
-        if (r.wire == d_bases) {
-            if (tables) *tables = r.tabled ? r.plan.W : 1u;
-            if (window_bits) *window_bits = r.tabled ? r.plan.width[0] : 0u;
-            if (bytes) *bytes = r.bytes;
+        if (r->wire == d_bases) {
+            if (tables) *tables = r->tabled ? r->plan.W : 1u;
+            if (window_bits) *window_bits = r->tabled ? r->plan.width[0] : 0u;
+            if (bytes) *bytes = r->bytes;
             return panda_success;
         }
     return panda_error_invalid_value;
@@ -200,25 +277,8 @@ panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, uns
 
 panda_error panda_msm_unregister_bases(const void *d_bases)
 {
-    std::vector<void *> to_free;
-    {
-        std::lock_guard<std::mutex> lock(g_registry_mutex);
-        for (size_t i = 0; i < g_registry.size();) {
-            if (g_registry[i].wire == d_bases) {
-                to_free.push_back(g_registry[i].converted);
-                g_registry.erase(g_registry.begin() + i);
-            } else
-                i++;
-        }
-    }
-    if (to_free.empty()) return panda_error_invalid_value;
-    (void)hipDeviceSynchronize();
-    hipError_t e = hipSuccess;
-    for (void *p : to_free) {
-        hipError_t f = hipFree(p);
-        if (f != hipSuccess) e = f;
-    }
-    return static_cast<panda_error>(e);
+    // an MSM that is executing with this registration on another host thread keeps it alive until it returns
+    return forget_if([d_bases](const RegisteredBases &r) { return r.wire == d_bases; }) ? panda_success : panda_error_invalid_value;
 }
 
 panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(0, cfg)); }
@@ -230,14 +290,14 @@ panda_error panda_msm_execute_bls12_381(const panda_msm_configuration cfg) { ret
 panda_error panda_msm_set_window_bits(unsigned window_bits)
 {
     if (window_bits > 16) return panda_error_invalid_value;
-    g_window_override = window_bits;
+    g_window_override.store(window_bits, std::memory_order_relaxed);
     return panda_success;
 }
 
 panda_error panda_msm_set_reduce_group(unsigned group)
 {
     if (group > 64) return panda_error_invalid_value;
-    g_reduce_group = group;
+    g_reduce_group.store(group, std::memory_order_relaxed);
     return panda_success;
 }
 

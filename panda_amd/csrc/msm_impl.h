@@ -46,20 +46,23 @@ struct MsmRegistration {
     int device;
     bool tabled;
     WindowPlan plan;
-    size_t bytes;
+    size_t bytes;            // converted rows / tables (what panda_msm_registered_info reports)
+    const uint32_t *samples; // REG_SAMPLES rows of the wire buffer as registered, kept behind the tables (stale-address check)
 };
+constexpr unsigned REG_SAMPLES = 64;
 
 struct MsmTuning {
     unsigned window_bits;  // plain-mode window width (already resolved by the policy)
     unsigned reduce_group; // 0 = built-in
 };
 
-// per-curve entry points (defined in msm_bn254.hip / msm_bls377.hip / msm_bls381.hip)
-hipError_t msm_execute_bn254(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
-hipError_t msm_execute_bls377(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
+// per-curve entry points (defined in msm_bn254.hip / msm_bls377.hip / msm_bls381.hip).  *stale is set when the caller's buffer
+// no longer matches the rows sampled at registration; the result written is then meaningless and msm.hip repeats the call
+hipError_t msm_execute_bn254(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
+hipError_t msm_execute_bls377(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
 hipError_t msm_build_registration_bn254(MsmRegistration &r, hipStream_t s);
 hipError_t msm_build_registration_bls377(MsmRegistration &r, hipStream_t s);
-hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms);
+hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
 hipError_t msm_build_registration_bls381(MsmRegistration &r, hipStream_t s);
 
 } // namespace panda
@@ -176,6 +179,28 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ w
         for (int k = 0; k < 2 * L; k++) o[k] = 0;
     }
     store_words<2 * L>(out + i * 2 * L, o);
+}
+
+// Rows of the caller's wire buffer remembered at registration and compared on every execute (msm.hip, "Staleness").
+// Sample t is row 0, row n-1, or a fixed pseudo-random row; block = REG_SAMPLES x 16 threads, lane l owns words l, l+16, ...
+__device__ __forceinline__ u64 sample_row(unsigned t, u64 n) { return t == 0 ? 0 : (t == 1 ? n - 1 : (((u64)t * 0x9E3779B97F4A7C15ull) >> 20) & (n - 1)); }
+
+__global__ void __launch_bounds__(panda::REG_SAMPLES * 16) k_take_samples(const u32 *__restrict__ wire, u32 *__restrict__ samples, u64 n, unsigned row_words)
+{
+    const unsigned t = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const u64 row = sample_row(t, n);
+    for (unsigned k = l; k < row_words; k += 16) samples[t * row_words + k] = wire[row * row_words + k];
+}
+
+__global__ void __launch_bounds__(panda::REG_SAMPLES * 16) k_check_samples(const u32 *__restrict__ wire, const u32 *__restrict__ samples, u64 n, unsigned row_words,
+                                                                          u32 *__restrict__ flag)
+{
+    const unsigned t = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const u64 row = sample_row(t, n);
+    int differs = 0;
+    for (unsigned k = l; k < row_words; k += 16) differs |= samples[t * row_words + k] != wire[row * row_words + k];
+    differs = __syncthreads_or(differs);
+    if (threadIdx.x == 0) *flag = differs ? 1u : 0u;
 }
 
 // first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
@@ -674,7 +699,7 @@ unsigned floor_log2(u64 v)
 }
 
 template <class C>
-hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegistration *registration, panda::MsmTuning tuning, float *phase_ms)
+hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegistration *registration, panda::MsmTuning tuning, float *phase_ms, bool *stale)
 {
     typedef typename C::Fq Fq;
     constexpr int PW = 4 * Fq::N;
@@ -718,7 +743,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
     const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
     const size_t sz_l1 = panda::align256(std::max((size_t)lists * slots * nblk, (size_t)2 * rc_rows + rc_cols) * PW * 4);
-    const size_t sz_win = panda::align256((size_t)lists * PW * 4);
+    const size_t sz_win = panda::align256((size_t)lists * PW * 4 + 4); // + the stale-registration flag, fetched with the window sums
     const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
     const unsigned long_cap = chunks / LONG_SPAN + 2;
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
@@ -750,7 +775,10 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
 
     PANDA_TRY(mark(0));
-    if (!registered)
+    u32 *d_stale = d_win + (size_t)lists * PW;
+    if (registered)
+        hipLaunchKernelGGL(k_check_samples, dim3(1), dim3(panda::REG_SAMPLES * 16), 0, stream, (const u32 *)cfg.bases, registration->samples, n, 2u * LQ, d_stale);
+    else
         hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
     panda::SortResult sorted{};
     const panda::SortEvents sort_events{ev[1], ev[2]};
@@ -782,9 +810,13 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
 
-    std::vector<u32> h_win((size_t)lists * PW);
-    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, (size_t)lists * PW * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<u32> h_win((size_t)lists * PW + 1, 0u);
+    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, ((size_t)lists * PW + (registered ? 1 : 0)) * 4, hipMemcpyDeviceToHost, stream));
     PANDA_TRY(hipStreamSynchronize(stream));
+    if (registered && h_win[(size_t)lists * PW] != 0) { // the caller's buffer is not what was registered: the sums above mean nothing
+        if (stale) *stale = true;
+        return hipSuccess;
+    }
 
     std::vector<Xyzz<Fq>> windows(lists);
     for (unsigned w = 0; w < lists; w++) {
@@ -830,8 +862,12 @@ hipError_t build_registration(panda::MsmRegistration &r, hipStream_t s)
     const size_t row = 2 * Fq::L * 4;
     const unsigned tables = r.tabled ? r.plan.W : 1u;
     r.bytes = (size_t)tables * n * row;
-    PANDA_TRY(hipMalloc(&r.converted, r.bytes));
+    const size_t tail = panda::align256(r.bytes);
+    PANDA_TRY(hipMalloc(&r.converted, tail + panda::REG_SAMPLES * row));
     u32 *t0 = (u32 *)r.converted;
+    u32 *samples = (u32 *)((char *)r.converted + tail);
+    r.samples = samples;
+    hipLaunchKernelGGL(k_take_samples, dim3(1), dim3(panda::REG_SAMPLES * 16), 0, s, (const u32 *)r.wire, samples, n, 2u * Fq::L);
     hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32 *)r.wire, t0, n);
     for (unsigned k = 1; k < tables; k++)
         hipLaunchKernelGGL(k_table_step<Fq>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, t0 + (size_t)(k - 1) * n * 2 * Fq::L,

@@ -154,6 +154,10 @@ template <class Code, class Fn>
 __device__ __forceinline__ void for_each_code(const Code *__restrict__ dw, u64 begin, u64 end, Fn f)
 {
     constexpr unsigned PER = 16 / sizeof(Code);
+    if (reinterpret_cast<uintptr_t>(dw + begin) & 15) { // rows of fewer than PER codes (n < 8 or 4) need not start on 16 bytes: one code per load
+        for (u64 a = begin + threadIdx.x; a < end; a += blockDim.x) f(a, (u32)dw[a]);
+        return;
+    }
     for (u64 a = begin + (u64)threadIdx.x * PER; a < end; a += (u64)blockDim.x * PER) {
         const uint4 v = *reinterpret_cast<const uint4 *>(dw + a);
         const u32 wv[4] = {v.x, v.y, v.z, v.w};

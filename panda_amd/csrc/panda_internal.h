@@ -41,10 +41,18 @@ struct Arena {
         return (char *)base + off;
     }
     hipError_t release();
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena(); // a host thread that exits without tear_down does not leak its scratch
 };
 
 Arena &thread_arena();
 hipError_t release_thread_arena();
+
+// drops every cached-bases registration whose buffer lies in the allocation `ptr` belongs to (msm.hip); called by
+// panda_free / panda_free_async before the memory goes back to the allocator
+void registry_forget_allocation(const void *ptr);
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

@@ -74,7 +74,11 @@ panda_error panda_malloc(void **ptr, size_t size) { return static_cast<panda_err
 
 panda_error panda_malloc_host(void **ptr, size_t size) { return static_cast<panda_error>(hipHostMalloc(ptr, size, hipHostMallocDefault)); }
 
-panda_error panda_free(void *ptr) { return static_cast<panda_error>(hipFree(ptr)); }
+panda_error panda_free(void *ptr)
+{
+    panda::registry_forget_allocation(ptr); // a cached-bases registration must not survive its buffer (msm.hip)
+    return static_cast<panda_error>(hipFree(ptr));
+}
 
 panda_error panda_free_host(void *ptr) { return static_cast<panda_error>(hipHostFree(ptr)); }
 
@@ -122,7 +126,11 @@ panda_error panda_malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool
     return static_cast<panda_error>(hipMallocFromPoolAsync(ptr, size, static_cast<hipMemPool_t>(pool.handle), static_cast<hipStream_t>(stream.handle)));
 }
 
-panda_error panda_free_async(void *ptr, panda_stream stream) { return static_cast<panda_error>(hipFreeAsync(ptr, static_cast<hipStream_t>(stream.handle))); }
+panda_error panda_free_async(void *ptr, panda_stream stream)
+{
+    panda::registry_forget_allocation(ptr);
+    return static_cast<panda_error>(hipFreeAsync(ptr, static_cast<hipStream_t>(stream.handle)));
+}
 
 panda_error panda_device_enable_peer_access(int device_id) { return static_cast<panda_error>(hipDeviceEnablePeerAccess(device_id, 0)); }
 

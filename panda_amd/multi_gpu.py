@@ -89,3 +89,86 @@ def all_to_all_slab(tensor, group=None):
     out = torch.empty_like(tensor)
     dist.all_to_all_single(out, tensor, group=group)
     return out
+
+
+def _slab_step(step: int, pstream, d_slab: int, d_scratch: int, omega: np.ndarray, log_n: int, log_ranks: int, rank: int) -> int:
+    """One device half of the sharded transform through the C ABI; returns the flag (1: the output sits in d_scratch)."""
+    lib = ffi.load()
+    flag = C.c_uint(7)
+    cfg = ffi.NttSlabConfiguration(pstream, C.c_void_p(d_slab), C.c_void_p(d_scratch), C.c_void_p(omega.ctypes.data), log_n, log_ranks, rank,
+                                   C.pointer(flag))
+    fn = lib.panda_ntt_slab_step1_bn254 if step == 1 else lib.panda_ntt_slab_step2_bn254
+    ffi.check(fn(cfg), "SchedulingErr")
+    assert flag.value in (0, 1)
+    return flag.value
+
+
+def _log2_exact(v: int) -> int:
+    assert v > 0 and v & (v - 1) == 0, "the rank count must be a power of two"
+    return v.bit_length() - 1
+
+
+def ntt_sharded(slab, scratch, omega, log_n: int, group=None, stream=None):
+    """The sharded BN254 transform of one rank, composed on the device:
+        panda_ntt_slab_step1_bn254  ->  all_to_all_single (RCCL over xGMI)  ->  panda_ntt_slab_step2_bn254.
+
+    `slab` holds this rank's decimated input X_r[j2] = x[r + G j2] (n/G elements of 32 bytes) and `scratch` is a buffer of
+    the same size; both are torch uint8 tensors on this rank's device and both are overwritten.  `omega` is the primitive
+    n-th root in wire form (host, 8 x u32).  Returns whichever of the two tensors holds this rank's output
+    y[k1 m + q m/G + k2'] at [k1][k2'] (q = rank, m = n/G).
+
+    Every device step runs on `stream` (default: torch's current stream); the collective is issued with that stream current,
+    so torch orders it after step 1 and step 2 after it.  With the gloo backend (CPU rehearsal of the N > 1 path) the
+    exchange is staged through host memory, the two device halves are the same kernels."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    g = _log2_exact(world)
+    om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+    assert slab.is_cuda and scratch.is_cuda and slab.numel() == scratch.numel() == ((1 << log_n) >> g) * 32
+    s = stream if stream is not None else torch.cuda.current_stream(slab.device)
+    pstream = ffi.PandaStream(s.cuda_stream)
+    with torch.cuda.stream(s):
+        flag = _slab_step(1, pstream, slab.data_ptr(), scratch.data_ptr(), om, log_n, g, rank)
+        src, dst = (scratch, slab) if flag else (slab, scratch)
+        if dist.get_backend(group) == "nccl":
+            dist.all_to_all_single(dst, src, group=group)  # chunk q of every rank -> rank q; each GPU pair has its own xGMI link
+        else:
+            recv = torch.empty(src.numel(), dtype=torch.uint8)
+            dist.all_to_all_single(recv, src.cpu(), group=group)
+            dst.copy_(recv)
+            s.synchronize()
+        flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, rank)
+    return src if flag else dst
+
+
+def ntt_sharded_one_process(slabs, scratches, omega, log_n: int, stream=None):
+    """The same composition with all G ranks played by one process on one GPU: the slabs go through step 1 one after the
+    other, the all-to-all is G x G device-to-device copies, then step 2.  It exists so that the buffer protocol around the
+    exchange (which of slab / scratch each step leaves its output in, the chunk layout) can be tested against the real
+    kernels on a one-GPU box.  Returns the list of output tensors, rank order."""
+    import torch
+
+    world = len(slabs)
+    g = _log2_exact(world)
+    om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+    s = stream if stream is not None else torch.cuda.current_stream(slabs[0].device)
+    pstream = ffi.PandaStream(s.cuda_stream)
+    outs = []
+    with torch.cuda.stream(s):
+        pairs = []
+        for r in range(world):
+            flag = _slab_step(1, pstream, slabs[r].data_ptr(), scratches[r].data_ptr(), om, log_n, g, r)
+            pairs.append((scratches[r], slabs[r]) if flag else (slabs[r], scratches[r]))
+        for q in range(world):  # what all_to_all_single delivers to rank q: chunk q of every rank, in rank order
+            dst = pairs[q][1].view(world, -1)
+            for j1 in range(world):
+                dst[j1].copy_(pairs[j1][0].view(world, -1)[q])
+        s.synchronize()
+        for q in range(world):
+            src, dst = pairs[q]
+            flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, q)
+            outs.append(src if flag else dst)
+    return outs

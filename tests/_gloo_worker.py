@@ -32,9 +32,27 @@ def main():
         total = multi_gpu.msm_sharded(partial, curve=cid)
         want = po.expected_from_linearity(cid, 0xBA5E, po.gen_scalars(po.FR_OF[cid], 0x5CA1, n))
         ok = (po.to_affine(cid, total.view(np.uint32)) == want).all()
+    elif what == "ntt_device":
+        # sharded NTT with the product's device halves: every rank drives cuda:0 through multi_gpu.ntt_sharded
+        # (step 1 -> all-to-all -> step 2); the exchange is gloo, staged through the host.  Needs a GPU.
+        fid, log_n = po.F_BN254_FR, int(sys.argv[2])
+        n = 1 << log_n
+        m = n // world
+        om = po.root_of_unity(fid, log_n)
+        x = po.gen_scalars(fid, 0x4E54, n)
+        dev = torch.device("cuda", 0)
+        slab = torch.from_numpy(multi_gpu.slab_of(x, world, rank).view(np.uint8).reshape(-1).copy()).to(dev)
+        scratch = torch.empty_like(slab)
+        out = multi_gpu.ntt_sharded(slab, scratch, om, log_n)
+        mine = out.cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        y = multi_gpu.natural_from_slab_outputs([t.numpy().view(np.uint32).reshape(m, 8) for t in gathered])
+        ok = (y == po.ntt(fid, x, om, log_n)).all()
     else:
-        # sharded NTT: the exchange and the layouts are the product's (multi_gpu.py); the two local steps are stood in
-        # by the oracle because their product implementation is a HIP kernel (covered by the -m gpu tests)
+        # sharded NTT on a box without a GPU: the exchange and the layouts are the product's (multi_gpu.py); the two local
+        # steps are stood in by the oracle because their product implementation is a HIP kernel ("ntt_device" above and
+        # the -m gpu tests run the real ones)
         fid, log_n = po.F_BN254_FR, int(sys.argv[2])
         n = 1 << log_n
         g = world.bit_length() - 1

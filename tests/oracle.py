@@ -163,6 +163,15 @@ def dft_naive(field_id, x, omega, log_n):
     return out
 
 
+def ntt_eval_at(field_id, x, omega, log_n, k):
+    """y[k] = sum_j x[j] omega^(jk) for one k, O(n)."""
+    x, omega = _u32(x), _u32(omega)
+    out = np.empty(FIELD_LC[field_id], dtype=np.uint32)
+    rc = lib().po_ntt_eval_at(field_id, _p(out), _p(x), _p(omega), C.c_uint(log_n), C.c_uint64(k))
+    assert rc == 0
+    return out
+
+
 def ntt_passes(field_id, x, omega, log_n):
     x, omega = _u32(x), _u32(omega)
     out = np.empty_like(x)

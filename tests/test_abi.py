@@ -98,6 +98,22 @@ def test_combine_partials(cid):
     assert (po.hom_to_affine(cid, hom.view(np.uint32)) == po.to_affine(cid, total.view(np.uint32))).all()
 
 
+def test_config1_host_entry_2_16_vs_oracle_16_bit_windows():
+    """BASELINE config 1 (BN254 MSM 2^16 random scalars/bases via the CPU host-debug path, no GPU): the product's
+    panda_msm_execute_bn254_host against the oracle's restatement of the reference algorithm at its own window width
+    (BIT_S = 16, msm_config.cuh:7; msm_host.cuh:267-370), plus the linearity identity.  test_msm_bn254_correctness_host
+    (tests/test.rs:115-194) stops at the same size."""
+    n = 1 << 16
+    bases = po.gen_bases(0, 116, n)
+    scalars = po.gen_scalars(po.F_BN254_FR, 216, n)
+    keep = scalars.copy()
+    want = po.msm_affine(0, bases, scalars, window_bits=16, threads=8)
+    assert (want == po.expected_from_linearity(0, 116, scalars)).all()
+    out = pgm.panda_msm_bn254_gpu_host(None, scalars, bases)
+    assert (po.to_affine(0, out.view(np.uint32)) == want).all()
+    assert (scalars == keep).all()
+
+
 def test_gpu_manager_helpers():
     assert pgm.log_2(1) == 0 and pgm.log_2(1024) == 10 and pgm.log_2(1500) == 10  # gpu_manager/common.rs:5-15
     assert pgm.FIELD_ELEMENT_LEN == 32

@@ -45,3 +45,11 @@ def test_msm_base_range_sharding_world4():
 @pytest.mark.parametrize("world,log_n", [(2, 8), (4, 9)])
 def test_ntt_slab_exchange_and_layout(world, log_n):
     _launch(world, "ntt", str(log_n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,log_n", [(2, 10), (2, 17), (4, 14)])
+def test_ntt_sharded_device_halves_over_gloo(world, log_n):
+    """The composed sharded transform (multi_gpu.ntt_sharded: step 1 -> all-to-all -> step 2) with the HIP kernels for both
+    local halves; the ranks share cuda:0 and exchange over gloo."""
+    _launch(world, "ntt_device", str(log_n))

@@ -221,6 +221,20 @@ def test_ntt_definition(fid):
         assert flag == ((log_n + 7) // 8) % 2
 
 
+@pytest.mark.parametrize("fid,log_n", [(po.F_BN254_FR, 0), (po.F_BN254_FR, 5), (po.F_BN254_FR, 11), (po.F_BLS377_FR, 9), (po.F_BLS381_FR, 9)])
+def test_ntt_single_output_evaluation(fid, log_n):
+    """po_ntt_eval_at (Horner, O(n) per output: the full-size spot check of the GPU tests) against the transform and the O(n^2) definition."""
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 77 + log_n, n)
+    y = po.ntt(fid, x, om, log_n)
+    if log_n <= 9:
+        assert (y == po.dft_naive(fid, x, om, log_n)).all()
+    for k in sorted({0, 1 % n, n // 2, n - 1, 37 % n}):
+        assert (po.ntt_eval_at(fid, x, om, log_n, k) == y[k]).all()
+    assert (po.ntt_eval_at(fid, x, om, log_n, n + 3) == y[3 % n]).all()  # k is taken mod n
+
+
 def test_bn254_omega_table_value():
     # bn254/paramter.cuh:251-258: omega of order 2^28 in Montgomery form
     om = po.root_of_unity(po.F_BN254_FR, 28)
