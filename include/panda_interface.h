@@ -178,6 +178,10 @@ const char *panda_msm_phase_name(unsigned phase);
 /* Inverse transform: runs the forward passes with omega^-1 and fuses the n^-1 scaling into the last pass.
  * d_omega is the FORWARD root (host pointer), as for _v1. */
 panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exec_cfg);
+/* Bit-reversed orderings (SURVEY 8f-4 "bit-reversed NTT variants"): the forward transform with y[k] stored at bitrev(k), and the inverse
+ * (n^-1 fused) of a buffer in that order back to natural-order coefficients.  Chaining them skips two permutations. */
+panda_error panda_ntt_execute_bn254_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bn254_inverse_bitrev_in(const panda_ntt_configuration_v1 exec_cfg);
 /* Coset transforms (additive): forward y[k] = sum_j x[j] g^j w^(jk), inverse x[j] = g^-j n^-1 sum_k y[k] w^(-jk); `shift` is a HOST pointer
  * to g in Montgomery form (32 bytes, non-zero), d_omega the forward root as for _v1.  In place on d_src/d_dst with the usual flag protocol. */
 panda_error panda_ntt_execute_bn254_coset(const panda_ntt_configuration_v1 exec_cfg, const void *shift);

@@ -101,7 +101,8 @@ __device__ __forceinline__ void store_elem(u32 *__restrict__ dst, const Fe<Fr> &
     d4[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
 }
 
-__device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); }
+__device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); } // bits >= 1
+__device__ __forceinline__ unsigned bitrev0(unsigned v, unsigned bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
 
 // LDS image of field elements as NL limb planes: element e lives at word pad(e) = e + (e >> 5) of each plane.
 // The one-word pad per 32 elements makes every access pattern of a pass conflict-free or 2-way at worst:
@@ -196,6 +197,8 @@ struct PassArgs {
     unsigned tile_elems;  // min(TILE, n)
     unsigned strided_out; // write output i of sub-transform blk to blk + i*S (the input's own layout)
     unsigned canonical;   // reduce the outputs to [0, p): the last pass of a transform; earlier passes stop at [0, 2p)
+    unsigned br_in;       // first pass only: the caller's input is in bit-reversed order (element j sits at bitrev(j))
+    unsigned br_out;      // last pass only: leave the output in bit-reversed order (y[k] goes to bitrev(k))
 };
 
 template <class Fr, int DEG>
@@ -219,10 +222,23 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
         pq.store(w, tid);
     }
     for (unsigned e = tid; e < TE; e += 512) {
-        const unsigned b = e % B, i = e / B;
+        unsigned b, i;
+        size_t src_index;
+        if (A.br_in) {
+            // element j = blk + i*S of the natural order sits at bitrev(j) = (bitrev(blk) << DEG) + bitrev(i): the 2^DEG inputs of
+            // a sub-transform are one contiguous run, read in storage order and dropped into LDS at their natural index
+            b = e / R;
+            const unsigned r = e % R;
+            i = bitrev(r, DEG);
+            src_index = ((size_t)bitrev0(blk0 + b, A.log_n - DEG) << DEG) + r;
+        } else {
+            b = e % B;
+            i = e / B;
+            src_index = (size_t)(blk0 + b) + (size_t)i * S;
+        }
         const unsigned blk = blk0 + b;
         Fe<Fr> v;
-        load_elem(v, A.x + ((size_t)blk + (size_t)i * S) * 8);
+        load_elem(v, A.x + src_index * 8);
         if (A.lgp != 0 || A.force_tw) {
             const unsigned k = blk & (p - 1);
             const unsigned m = k * i;
@@ -254,24 +270,34 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
     constexpr int FB = Rounds<Fr, DEG, 0, 2>::FINAL;
     static_assert(FB < 512, "final bound must fit fe_reduce_small (values below 2^9 p)");
     for (unsigned e = tid; e < TE; e += 512) {
-        unsigned b, i;
+        unsigned b, i, lds_i;
         size_t dst_index;
-        if (A.strided_out) {
-            b = e % B;
-            i = e / B;
-            dst_index = (size_t)(blk0 + b) + (size_t)i * S;
-        } else if (A.lgp == 0) {
+        if (A.br_out) {
+            // last pass (lgp + DEG == log_n, or a single pass): y[blk + i p] goes to bitrev(blk + i p) = (bitrev(blk) << DEG) + bitrev(i);
+            // LDS holds the outputs in bit-reversed order already, so a sub-transform leaves as one contiguous run, copied straight out
             b = e / R;
-            i = e % R;
-            dst_index = ((size_t)(blk0 + b) << DEG) + i;
+            lds_i = e % R;
+            i = lds_i;
+            dst_index = ((size_t)bitrev0(blk0 + b, A.lgp) << DEG) + lds_i;
         } else {
-            b = e % B;
-            i = e / B;
-            const unsigned blk = blk0 + b, k = blk & (p - 1);
-            dst_index = ((size_t)(blk - k) << DEG) + k + (size_t)i * p;
+            if (A.strided_out) {
+                b = e % B;
+                i = e / B;
+                dst_index = (size_t)(blk0 + b) + (size_t)i * S;
+            } else if (A.lgp == 0) {
+                b = e / R;
+                i = e % R;
+                dst_index = ((size_t)(blk0 + b) << DEG) + i;
+            } else {
+                b = e % B;
+                i = e / B;
+                const unsigned blk = blk0 + b, k = blk & (p - 1);
+                dst_index = ((size_t)(blk - k) << DEG) + k + (size_t)i * p;
+            }
+            lds_i = bitrev(i, DEG);
         }
         Fe<Fr> v;
-        u.load(v, b * R + bitrev(i, DEG));
+        u.load(v, b * R + lds_i);
         fe_reduce_small_2p(v);
         if (A.canonical) fe_reduce_once(v); // between passes < 2p is enough: it fits the 32 bytes and the next pass's bounds
         store_elem(A.y + dst_index * 8, v);
@@ -413,7 +439,7 @@ thread_local TwiddleCache g_twiddles;
 // `build` = false reuses the tables already sitting in `arena` (same carve order).
 template <class Fr, class Alloc>
 hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
-                      unsigned *passes_out, bool build = true)
+                      unsigned *passes_out, bool build = true, bool br_in = false, bool br_out = false)
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
@@ -438,6 +464,8 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
         a.force_tw = (scale && last) ? 1 : 0;
         a.strided_out = 0;
         a.canonical = last ? 1 : 0;
+        a.br_in = (br_in && passes == 0) ? 1 : 0;
+        a.br_out = (br_out && last) ? 1 : 0;
         Fe<Fr> base;
         if (build) {
             fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
@@ -479,7 +507,8 @@ void inverse_parameters(Fe<Fr> &omega, Fe<Fr> &scale, u64 n)
 }
 
 template <class Fr>
-hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omega_wire, unsigned log_n, unsigned *flag, bool inverse)
+hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omega_wire, unsigned log_n, unsigned *flag, bool inverse, bool br_in = false,
+                   bool br_out = false)
 {
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
@@ -500,7 +529,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
         tw.used = 0;
     tw.valid = false;
     unsigned passes = 0;
-    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit));
+    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit, br_in, br_out));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
     memcpy(tw.key, key, sizeof(key));
@@ -659,6 +688,21 @@ panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 cfg
 {
     return static_cast<panda_error>(
         ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+}
+
+// Orderings a prover's polynomial pipeline chains without ever materialising the natural order in between: the forward
+// transform leaves y[k] at bitrev(k) (the last pass copies its LDS tile straight out), the inverse takes such a buffer
+// (the first pass reads contiguous runs) and returns natural-order coefficients, n^-1 fused.  Same passes, same flag protocol.
+panda_error panda_ntt_execute_bn254_bitrev_out(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false, false, true));
+}
+
+panda_error panda_ntt_execute_bn254_inverse_bitrev_in(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true, true, false));
 }
 
 panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg)); }

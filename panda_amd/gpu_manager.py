@@ -431,3 +431,10 @@ def panda_ntt_bls12_377_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, 
 def panda_intt_bn254_gpu(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int) -> int:
     """Additive: inverse transform with the n^-1 scaling fused (panda_ntt_execute_bn254_inverse)."""
     return _ntt(gm, scalars, log_n, ffi.load().panda_ntt_execute_bn254_inverse, omega)
+
+
+def panda_ntt_bn254_gpu_bitrev(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:
+    """Additive: forward transform leaving y[k] at bitrev(k), or (inverse=True) the inverse of a buffer in that order back to
+    natural-order coefficients with n^-1 fused.  In place on the caller's buffer like panda_ntt_bn254_gpu_v1."""
+    lib = ffi.load()
+    return _ntt(gm, scalars, log_n, lib.panda_ntt_execute_bn254_inverse_bitrev_in if inverse else lib.panda_ntt_execute_bn254_bitrev_out, omega)

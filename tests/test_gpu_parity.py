@@ -310,6 +310,28 @@ def test_ntt_v1_vs_oracle(gm, log_n):
     assert (back == x).all()
 
 
+@pytest.mark.parametrize("log_n", [0, 1, 3, 7, 8, 9, 12, 16, 17, 20])
+def test_ntt_bit_reversed_orderings(gm, log_n):
+    """SURVEY 8f-4: forward with bit-reversed output (y[k] at bitrev(k)) equals the oracle's natural-order transform permuted;
+    the inverse from bit-reversed input returns the coefficients; the flag protocol is unchanged."""
+    fid = po.F_BN254_FR
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 3100 + log_n, n)
+    perm = np.array([int(format(k, f"0{log_n}b")[::-1], 2) if log_n else 0 for k in range(n)])
+    want = po.ntt(fid, x, om, log_n)
+    buf = x.copy()
+    flag = pgm.panda_ntt_bn254_gpu_bitrev(gm, buf, om, log_n)
+    assert flag == ((log_n + 7) // 8) % 2
+    assert (buf[perm] == want).all()  # buf[bitrev(k)] = y[k]
+    pgm.panda_ntt_bn254_gpu_bitrev(gm, buf, om, log_n, inverse=True)
+    assert (buf == x).all()
+    # the inverse alone, from the oracle's output permuted on the host
+    buf = np.ascontiguousarray(want[perm])  # position bitrev(k) holds y[k] (the permutation is an involution)
+    pgm.panda_ntt_bn254_gpu_bitrev(gm, buf, om, log_n, inverse=True)
+    assert (buf == x).all()
+
+
 def test_ntt_setup_then_execute(gm):
     """init_ntt + panda_ntt_bn254_gpu (wrapper.rs:199-210, unit.rs:418-479): omega from the global setup."""
     fid, log_n = po.F_BN254_FR, 11

@@ -45,12 +45,32 @@ def main():
         factor = GATHER_FACTOR if k in GATHER_KERNELS else 2.0
         rows.append((k, len(fv), f, factor * f, w, factor * f + w))
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_bytes.csv"), "w") as o:
-        o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt --no-compare (BN254 MSM 2^24, precomputed tables)\n")
+        o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-config4 --no-extra-configs (BN254 MSM 2^24, precomputed tables; NTT 2^24)\n")
         o.write("# bytes per launch = counter (KB) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane streaming reads),\n# except k_accumulate: its reads are 64-byte row gathers, which the counter tallies exactly (calibrated with tools/ubench_gather.hip: 4.295 GB requested, 4.295 GB counted);\n")
         o.write("# k_convert_bases calibrates the correction: it reads 2^24 * 64 B = 1.074 GB\n")
         o.write("kernel,launches,fetch_size_raw_bytes,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
         for r in rows:
             o.write("%s,%d,%.0f,%.0f,%.0f,%.0f\n" % r)
+    sq_files = glob.glob(os.path.join(ROOT, "gpurun_out/prof_sq/**/*counter_collection.csv"), recursive=True)
+    if sq_files:
+        # SQ issue counters per kernel: mean over the launches of (sum over the chip).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+        # quad-cycles per wave (MI355X_MICROARCH.md); the ratios to SQ_WAVE_CYCLES are what DESIGN.md quotes.
+        sq = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(latest("gpurun_out/prof_sq/**/*counter_collection.csv"))):
+            sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass, tools/profile_bench.sh) of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-config4 --no-extra-configs\n")
+            o.write("# per launch, summed over the chip, mean over launches; the last columns are ratios to SQ_WAVE_CYCLES and VALU instructions per wave\n")
+            o.write("kernel,launches," + ",".join(names) + ",active_valu_over_wave_cycles,wait_any_over_wave_cycles,wait_inst_any_over_wave_cycles,insts_valu_per_wave\n")
+            for k in sorted(sq):
+                if not re.match(r"k\d?_", k):
+                    continue
+                m = {nm: (sum(sq[k][nm]) / len(sq[k][nm]) if sq[k][nm] else 0.0) for nm in names}
+                wc = m["SQ_WAVE_CYCLES"] or 1.0
+                o.write("%s,%d,%s,%.4f,%.4f,%.4f,%.1f\n" % (k, len(sq[k]["SQ_WAVE_CYCLES"]), ",".join("%.0f" % m[nm] for nm in names), m["SQ_ACTIVE_INST_VALU"] / wc,
+                                                           m["SQ_WAIT_ANY"] / wc, m["SQ_WAIT_INST_ANY"] / wc, m["SQ_INSTS_VALU"] / (m["SQ_WAVES"] or 1.0)))
+        print(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.csv")).read())
     acc = [r for r in rows if r[0] == "k_accumulate"][0]
     json.dump({"round": tag, "log_n": 24, "k_accumulate_hbm_bytes_per_launch": acc[5], "fetch_corrected": acc[3], "write": acc[4],
                "source": f"profiles/{tag}_pmc_hbm_bytes.csv"}, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
