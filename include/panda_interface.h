@@ -166,6 +166,16 @@ panda_error panda_msm_precompute_bases(unsigned curve, const void *d_bases, unsi
 /* what is registered for d_bases: number of tables (1 = converted copy only), window bits (0 if none), device bytes held */
 panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, unsigned *window_bits, size_t *bytes);
 
+/* Upload / execute pipeline inside ONE call (the reference's h2d / exec streams, wrapper.rs:260-273 and unit.rs:17-29, run
+ * one after the other).  exec_cfg is as for panda_msm_execute_*; exec_cfg.scalars is the caller's DEVICE buffer of n x 32 bytes and
+ * h_scalars the HOST source it is filled from (pinned memory lets the copies run beside the kernels).  Against registered bases the
+ * scalars are cut into `ranges` (1..8) contiguous point ranges of n/2^(R-1), n/2^(R-1), n/2^(R-2), ..., n/2 points: range r+1 is copied
+ * on h2d_stream while range r runs digits -> sort -> accumulate on exec_cfg.stream against its own rows of the registered tables; each
+ * range's buckets are added into a running total on the device, which is reduced once.  Unregistered bases, or fewer than 2^16 points
+ * in the first range, reduce the number of ranges, down to one copy followed by the ordinary call.  h_scalars == NULL skips the copies
+ * and runs the same schedule on resident scalars.  Synchronous on return like panda_msm_execute_*; same group element.  curve: 0 / 1 / 2. */
+panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configuration exec_cfg, const void *h_scalars, unsigned ranges, panda_stream h2d_stream);
+
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
 panda_error panda_msm_set_window_bits(unsigned window_bits);
 /* buckets per thread in the bucket-reduction kernel, for experiments: 0 = built-in policy */
@@ -216,6 +226,10 @@ typedef struct panda_ntt_slab_configuration
 /* step 1: local column transforms + inter-slab twiddle; step 2 (after the all-to-all): local row transforms */
 panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg);
+/* the same steps, enqueued on cfg.stream without waiting (flag is valid on return): step 1 -> all-to-all -> step 2 on one stream needs one
+ * synchronisation at the end */
+panda_error panda_ntt_slab_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 
 /* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377 */
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);

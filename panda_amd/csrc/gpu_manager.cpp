@@ -216,6 +216,9 @@ PandaGpuError run_msm(const PandaGpuManager &gm, void *d_scalars, void *d_bases,
 
 } // namespace
 
+// point ranges of a single call's upload / execute pipeline: n/2^(R-1), n/2^(R-1), n/2^(R-2), ..., n/2 points
+unsigned pipeline_ranges(uint32_t log_n) { return log_n >= 24 ? 5u : (log_n >= 22 ? 4u : (log_n >= 20 ? 3u : (log_n >= 18 ? 2u : 1u))); }
+
 PandaGpuError panda_msm_bn254_gpu(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result)
 {
     void *d_scalars = nullptr, *d_bases = nullptr;
@@ -231,11 +234,32 @@ PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, B
 {
     void *d_bases = gm.get_params_bases_ptr_mut(bases_index);
     if (!d_bases) return PandaGpuError::BasesIndexErr;
+    const uint32_t log_n = log_2(scalars.len / FIELD_ELEMENT_LEN);
+    const unsigned ranges = pipeline_ranges(log_n);
+    bool registered = false;
+    for (void *p : gm.registered_bases) registered = registered || p == d_bases;
+    if (registered && ranges > 1) {
+        // additive: upload and execution pipelined inside the one call -- the scalars cross PCIe in point ranges on the
+        // h2d stream while the previous range is being accumulated on the exec stream (panda_msm_execute_from_host)
+        const size_t result_buf_len = FIELD_ELEMENT_LEN * 3;
+        void *d_scalars = nullptr, *d_result = nullptr;
+        PandaGpuError e = malloc_from_pool_async(&d_scalars, ((size_t)1 << log_n) * FIELD_ELEMENT_LEN, gm.get_mem_pool(), gm.get_h2d_stream());
+        if (e != PandaGpuError::Ok) return e;
+        if ((e = malloc_from_pool_async(&d_result, result_buf_len, gm.get_mem_pool(), gm.get_h2d_stream())) != PandaGpuError::Ok) return e;
+        if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
+        panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_bases, d_scalars, d_result, log_n, gm.get_msm_result_coordinate_type()};
+        const bool ran = panda_msm_execute_from_host(0, cfg, scalars.data, ranges, gm.get_h2d_stream()) == 0;
+        result->resize(result_buf_len);
+        const bool copied = ran && panda_memcpy(result->data(), d_result, result_buf_len) == 0;
+        (void)panda_free(d_scalars);
+        (void)panda_free(d_result);
+        return !ran ? PandaGpuError::SchedulingErr : (copied ? PandaGpuError::Ok : PandaGpuError::CreateContextError);
+    }
     void *d_scalars = nullptr;
     PandaGpuError e = memory_alloc_and_copy(gm, scalars, gm.get_h2d_stream(), &d_scalars);
     if (e != PandaGpuError::Ok) return e;
     if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
-    return run_msm(gm, d_scalars, d_bases, log_2(scalars.len / FIELD_ELEMENT_LEN), true, false, result);
+    return run_msm(gm, d_scalars, d_bases, log_n, true, false, result);
 }
 
 // additive: the upload of batch k+1 runs on the h2d stream while batch k executes on the exec stream

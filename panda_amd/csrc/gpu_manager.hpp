@@ -121,6 +121,8 @@ PandaGpuError memcpy_async(void *dst, const void *src, size_t size, panda_stream
 PandaGpuError free_async(void *ptr, panda_stream stream);
 PandaGpuError memory_alloc_and_copy(const PandaGpuManager &gm, Bytes h_values, panda_stream stream, void **d_values);
 
+unsigned pipeline_ranges(uint32_t log_n); // additive: ranges the with_cached_bases call pipelines its upload in (1 = not pipelined)
+
 // gpu_manager/unit.rs -- results are 96 bytes X||Y||Z (Montgomery limbs)
 PandaGpuError panda_msm_bn254_gpu(const PandaGpuManager &gm, Bytes scalars, Bytes bases, std::vector<uint8_t> *result);                    // :10-101
 PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, Bytes scalars, size_t bases_index, std::vector<uint8_t> *result);   // :103-188

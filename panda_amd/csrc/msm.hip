@@ -166,29 +166,29 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
     return best;
 }
 
-hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale)
+hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale, const panda::MsmPipeline *pipe)
 {
     const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group.load(std::memory_order_relaxed)};
     switch (curve) {
-    case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale);
-    case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale);
-    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms, stale);
+    case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
+    case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
+    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms, stale, pipe);
     }
 }
 
-hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg)
+hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmPipeline *pipe = nullptr)
 {
     if (cfg.log_scalars_count > 26 || !cfg.bases) return hipErrorInvalidValue;
     const RegisteredPtr reg = lookup_registered(cfg.bases, cfg.log_scalars_count, curve); // held for the whole call
     bool stale = false;
-    hipError_t e = msm_execute_on(curve, cfg, reg.get(), &stale);
+    hipError_t e = msm_execute_on(curve, cfg, reg.get(), &stale, pipe);
     if (e == hipSuccess && stale) {
         // the buffer no longer holds the bases it held when it was registered (freed and reallocated behind our back):
         // the entry is dropped and the call answered from the caller's buffer as it is now
         printf("[panda-hip] registered bases at %p changed since registration: registration dropped, converting per call\n", cfg.bases);
         const RegisteredBases *gone = reg.get();
         forget_if([gone](const RegisteredBases &r) { return &r == gone; });
-        e = msm_execute_on(curve, cfg, nullptr, nullptr);
+        e = msm_execute_on(curve, cfg, nullptr, nullptr, pipe);
     }
     return e;
 }
@@ -286,6 +286,13 @@ panda_error panda_msm_execute_bn254(const panda_msm_configuration cfg) { return 
 panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(1, cfg)); }
 
 panda_error panda_msm_execute_bls12_381(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(2, cfg)); }
+
+panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configuration cfg, const void *h_scalars, unsigned ranges, panda_stream h2d_stream)
+{
+    if (curve > 2) return panda_error_invalid_value;
+    const panda::MsmPipeline pipe{h_scalars, ranges, static_cast<hipStream_t>(h2d_stream.handle)};
+    return static_cast<panda_error>(msm_execute(curve, cfg, &pipe));
+}
 
 panda_error panda_msm_set_window_bits(unsigned window_bits)
 {

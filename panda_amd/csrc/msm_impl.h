@@ -56,13 +56,26 @@ struct MsmTuning {
     unsigned reduce_group; // 0 = built-in
 };
 
+// Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
+// upload and execution): the scalars are cut into contiguous point ranges; range r+1 crosses PCIe on `h2d` while range r runs
+// digits -> sort -> accumulate against its own rows of the registered tables; each range's fix-up adds its buckets into the running
+// total on the device, which is reduced once.  h_scalars == nullptr runs the same chunked schedule on scalars that are already resident.
+struct MsmPipeline {
+    const void *h_scalars; // host (ideally pinned) source of the n x 32 B scalars, copied into cfg.scalars range by range
+    unsigned ranges;       // number of point ranges R (1 = whole call at once): n/2^(R-1), n/2^(R-1), n/2^(R-2), ..., n/2 points
+    hipStream_t h2d;       // stream the copies are issued on
+};
+
 // per-curve entry points (defined in msm_bn254.hip / msm_bls377.hip / msm_bls381.hip).  *stale is set when the caller's buffer
 // no longer matches the rows sampled at registration; the result written is then meaningless and msm.hip repeats the call
-hipError_t msm_execute_bn254(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
-hipError_t msm_execute_bls377(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
+hipError_t msm_execute_bn254(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale,
+                              const MsmPipeline *pipe);
+hipError_t msm_execute_bls377(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale,
+                              const MsmPipeline *pipe);
 hipError_t msm_build_registration_bn254(MsmRegistration &r, hipStream_t s);
 hipError_t msm_build_registration_bls377(MsmRegistration &r, hipStream_t s);
-hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale);
+hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale,
+                              const MsmPipeline *pipe);
 hipError_t msm_build_registration_bls381(MsmRegistration &r, hipStream_t s);
 
 } // namespace panda
@@ -345,9 +358,11 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
 constexpr unsigned LONG_SPAN = 128;
 constexpr unsigned LONG_BLOCKS = 256; // workgroups per window that serve the queue
 
-template <class F>
-__global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB,
-                                               unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
+// MERGE (point-range chunks, every range after the first): `bucket_acc` holds this range's buckets -- only the non-empty ones are
+// defined -- and every non-empty bucket is added into `total`, the running sum over the ranges, here instead of in a pass of its own.
+template <class F, bool MERGE>
+__global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, u32 *__restrict__ total,
+                                               unsigned NB, unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
@@ -355,10 +370,13 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
     if (b >= NB) return;
     const u32 *ow = off + (u64)w * (NB + 1);
     const u32 s = ow[b], e = ow[b + 1];
-    if (s == e) return; // empty: bucket_acc was zeroed (identity)
+    if (s == e) return; // empty: bucket_acc was zeroed (identity) / nothing to add to the total
     const u32 t0 = s / K, t1 = (e - 1) / K;
-    if (t0 == t1) return; // lies inside one chunk: written by k_accumulate
-    if (t1 - t0 > LONG_SPAN) {
+    Xyzz<F> acc, q;
+    if (t0 == t1) { // lies inside one chunk: written by k_accumulate
+        if (!MERGE) return;
+        load_xyzz<F>(acc, bucket_acc + ((u64)w * NB + b) * PW);
+    } else if (t1 - t0 > LONG_SPAN) {
         u32 slot = atomicAdd(&long_count[w], 1u); // a handful per window at most: (t1 - t0) > LONG_SPAN bounds it by chunks / LONG_SPAN
         if (slot < long_cap) {
             u32 *e3 = long_list + ((u64)w * long_cap + slot) * 3;
@@ -367,20 +385,25 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
             e3[2] = t1;
         }
         return;
+    } else {
+        const u32 *pw = parts + (u64)w * chunks * 2 * PW;
+        load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
+        for (u32 t = t0 + 1; t <= t1; t++) {
+            load_xyzz<F>(q, pw + (u64)t * 2 * PW);
+            xyzz_add(acc, q);
+        }
     }
-    const u32 *pw = parts + (u64)w * chunks * 2 * PW;
-    Xyzz<F> acc, q;
-    load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
-    for (u32 t = t0 + 1; t <= t1; t++) {
-        load_xyzz<F>(q, pw + (u64)t * 2 * PW);
+    if (MERGE) {
+        load_xyzz<F>(q, total + ((u64)w * NB + b) * PW);
         xyzz_add(acc, q);
-    }
-    store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+        store_xyzz<F>(total + ((u64)w * NB + b) * PW, acc);
+    } else
+        store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
 }
 
-// one workgroup per queued bucket: 256 threads stride over its pieces, then an LDS tree
+// one workgroup per queued bucket: 256 threads stride over its pieces, then an LDS tree; the result replaces dst[b], or is added to it (ADD)
 template <class F>
-__global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, unsigned NB, unsigned chunks,
+__global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ parts, u32 *__restrict__ dst, unsigned add, unsigned NB, unsigned chunks,
                                                     const u32 *__restrict__ long_count, const u32 *__restrict__ long_list, unsigned long_cap)
 {
     constexpr int PW = 4 * F::N;
@@ -407,7 +430,13 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
             }
             __syncthreads();
         }
-        if (t == 0) store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+        if (t == 0) {
+            if (add) {
+                load_xyzz<F>(q, dst + ((u64)w * NB + b) * PW);
+                xyzz_add(acc, q);
+            }
+            store_xyzz<F>(dst + ((u64)w * NB + b) * PW, acc);
+        }
         __syncthreads();
     }
 }
@@ -699,7 +728,8 @@ unsigned floor_log2(u64 v)
 }
 
 template <class C>
-hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegistration *registration, panda::MsmTuning tuning, float *phase_ms, bool *stale)
+hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegistration *registration, panda::MsmTuning tuning, float *phase_ms, bool *stale,
+                       const panda::MsmPipeline *pipe)
 {
     typedef typename C::Fq Fq;
     constexpr int PW = 4 * Fq::N;
@@ -716,12 +746,37 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const unsigned W = plan.W;
     const unsigned c = plan.width[0]; // widest window
     const unsigned NB = 1u << (c - 1);
-    const unsigned lists = tabled ? 1u : W;         // independent bucket spaces
-    const u64 stride = tabled ? (u64)W << log_n : n; // entries per list (upper bound)
-    const unsigned lg = floor_log2(stride);
-    // sorted entries per accumulate thread (64 ... 256 measure the same at 2^24: fewer pieces to merge against fewer threads)
-    const unsigned K = lg >= 24 ? 128 : (lg >= 22 ? 64 : (lg >= 16 ? 32 : 16));
-    const unsigned chunks = (unsigned)((stride + K - 1) / K);
+    const unsigned lists = tabled ? 1u : W; // independent bucket spaces
+    // Point ranges: only against registered bases (the converted rows / tables exist for every range already), ranges of at least
+    // 2^16 points, and only where the three-level sort has a geometry for the range sizes.  R ranges hold n/2^(R-1), n/2^(R-1),
+    // n/2^(R-2), ..., n/2 points: the first upload -- the only one nothing runs beside -- is short, and every later range is at most
+    // twice its predecessor, so its upload (PCIe moves a range about 1.9x faster than the kernels consume one) hides behind it.
+    unsigned nranges = (pipe && registered) ? std::min(std::max(pipe->ranges, 1u), 8u) : 1u;
+    auto ranges_ok = [&](unsigned R) {
+        if (log_n < (R - 1) + 16) return false;
+        for (unsigned lc = log_n - (R - 1); tabled && lc < log_n; lc++)
+            if (!panda::msm_sort_tabled_supported(lc, plan)) return false;
+        return true;
+    };
+    while (nranges > 1 && !ranges_ok(nranges)) nranges--;
+    auto range_log = [&](unsigned r) { return nranges == 1 ? log_n : log_n - (r == 0 ? nranges - 1 : nranges - r); };
+    auto range_row0 = [&](unsigned r) { return (nranges == 1 || r == 0) ? (u64)0 : (u64)1 << (log_n - (nranges - r)); };
+    struct RangeGeom {
+        u64 stride;               // entries per list (upper bound)
+        unsigned K, chunks, long_cap; // sorted entries per accumulate thread, accumulate threads per list, queue slots for long buckets
+    };
+    auto range_geom = [&](unsigned log_c) {
+        RangeGeom g;
+        g.stride = tabled ? (u64)W << log_c : (u64)1 << log_c;
+        // sorted entries per accumulate thread: as many as leave about 2^20 threads over all lists -- six rounds of the chip's
+        // 2^18 resident threads at four waves per SIMD, so neither a half-empty chip nor a half-empty last round costs much
+        // (a 2^21-point range at K = 128 kept three waves per SIMD busy: 2.4 ms instead of 1.8); 64 ... 256 measure the same at 2^24
+        const u64 per_k = ((u64)lists * g.stride) >> 20;
+        g.K = per_k >= 128 ? 128 : (per_k >= 64 ? 64 : (per_k >= 32 ? 32 : 16));
+        g.chunks = (unsigned)((g.stride + g.K - 1) / g.K);
+        g.long_cap = g.chunks / LONG_SPAN + 2;
+        return g;
+    };
     unsigned log_group = NB >= (1u << 18) ? 3u : 2u; // log2 of the buckets per k_reduce_groups thread
     if (tuning.reduce_group) log_group = floor_log2(tuning.reduce_group);
     const unsigned group = 1u << log_group;
@@ -738,20 +793,25 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
 
     // ---- scratch
     const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
-    const size_t sz_sort = tabled ? panda::msm_sort_tabled_bytes(log_n, plan) : panda::msm_sort_plain_bytes(log_n, plan);
+    size_t sz_sort = 0, sz_parts = 0, sz_llist = 0; // maxima over the range sizes in use (neither is monotonic in the size by construction)
+    for (unsigned r = 0; r < nranges; r++) {
+        const unsigned lc = range_log(r);
+        const RangeGeom g = range_geom(lc);
+        sz_sort = std::max(sz_sort, tabled ? panda::msm_sort_tabled_bytes(lc, plan) : panda::msm_sort_plain_bytes(lc, plan));
+        sz_parts = std::max(sz_parts, panda::align256((size_t)lists * g.chunks * 2 * PW * 4));
+        sz_llist = std::max(sz_llist, panda::align256((size_t)lists * g.long_cap * 3 * 4));
+    }
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
-    const size_t sz_parts = panda::align256((size_t)lists * chunks * 2 * PW * 4);
     const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
     const size_t sz_l1 = panda::align256(std::max((size_t)lists * slots * nblk, (size_t)2 * rc_rows + rc_cols) * PW * 4);
     const size_t sz_win = panda::align256((size_t)lists * PW * 4 + 4); // + the stale-registration flag, fetched with the window sums
     const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
-    const unsigned long_cap = chunks / LONG_SPAN + 2;
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
-    const size_t sz_llist = panda::align256((size_t)lists * long_cap * 3 * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_sort + sz_bacc + sz_parts + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + sz_lcount + sz_llist + 8192));
+    PANDA_TRY(arena.reserve(sz_bases + sz_sort + (nranges > 1 ? 2 : 1) * sz_bacc + sz_parts + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + sz_lcount + sz_llist + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
+    u32 *d_bacc_range = nranges > 1 ? (u32 *)arena.take(sz_bacc) : d_bacc; // buckets of the range in flight, added into d_bacc by its fix-up
     u32 *d_parts = (u32 *)arena.take(sz_parts);
     u32 *d_gsum = (u32 *)arena.take(sz_gsum);
     u32 *d_gtsum = (u32 *)arena.take(sz_gsum);
@@ -760,13 +820,17 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     u32 *d_slots = (u32 *)arena.take(sz_slots);
     u32 *d_lcount = (u32 *)arena.take(sz_lcount);
     u32 *d_llist = (u32 *)arena.take(sz_llist);
-    if (!d_bases || !d_bacc || !d_parts || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots || !d_lcount || !d_llist) return hipErrorOutOfMemory;
+    if (!d_bases || !d_bacc || !d_bacc_range || !d_parts || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots || !d_lcount || !d_llist) return hipErrorOutOfMemory;
+    const size_t sort_mark = arena.used; // every range's sort carves its scratch from here again
 
     struct PhaseEvents { // destroyed on every exit path
         hipEvent_t ev[8] = {};
+        std::vector<hipEvent_t> uploaded;
         ~PhaseEvents()
         {
             for (auto &e : ev)
+                if (e) (void)hipEventDestroy(e);
+            for (auto &e : uploaded)
                 if (e) (void)hipEventDestroy(e);
         }
     } phase_events;
@@ -774,28 +838,60 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
     auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
 
+    // upload of range r on the copy stream (a pageable source makes the call block until the range is staged, a pinned one returns at once)
+    const char *h_scalars = pipe ? (const char *)pipe->h_scalars : nullptr;
+    if (h_scalars) {
+        phase_events.uploaded.assign(nranges, nullptr);
+        for (auto &e : phase_events.uploaded) PANDA_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    auto upload = [&](unsigned r) -> hipError_t {
+        const size_t first = (size_t)range_row0(r) * 32, bytes = ((size_t)1 << range_log(r)) * 32;
+        PANDA_TRY(hipMemcpyAsync((char *)cfg.scalars + first, h_scalars + first, bytes, hipMemcpyHostToDevice, pipe->h2d));
+        return hipEventRecord(phase_events.uploaded[r], pipe->h2d);
+    };
+
     PANDA_TRY(mark(0));
+    if (h_scalars) PANDA_TRY(upload(0));
     u32 *d_stale = d_win + (size_t)lists * PW;
     if (registered)
         hipLaunchKernelGGL(k_check_samples, dim3(1), dim3(panda::REG_SAMPLES * 16), 0, stream, (const u32 *)cfg.bases, registration->samples, n, 2u * LQ, d_stale);
     else
         hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
-    panda::SortResult sorted{};
-    const panda::SortEvents sort_events{ev[1], ev[2]};
-    if (tabled)
-        PANDA_TRY(panda::msm_sort_tabled(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
-    else
-        PANDA_TRY(panda::msm_sort_plain(stream, arena, curve, cfg.scalars, log_n, plan, sort_events, &sorted));
-    if (sorted.lists != lists || sorted.NB != NB || sorted.stride != stride) return hipErrorInvalidValue;
-    PANDA_TRY(mark(3));
-    PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
-    hipLaunchKernelGGL(k_accumulate<Fq>, dim3((chunks + 127) / 128, lists), dim3(128), 0, stream, d_bases, sorted.sorted, sorted.off, d_bacc, d_parts, stride,
-                       NB, K, chunks);
-    PANDA_TRY(mark(4));
-    PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
-    hipLaunchKernelGGL(k_fixup<Fq>, dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, d_bacc, NB, K, chunks, d_lcount, d_llist,
-                       long_cap);
-    hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, NB, chunks, d_lcount, d_llist, long_cap);
+    for (unsigned r = 0; r < nranges; r++) { // phases 1..4 of a call in ranges are timed on its last (largest) range
+        const bool last = r + 1 == nranges;
+        const unsigned log_c = range_log(r);
+        const u64 row0 = range_row0(r);
+        const RangeGeom g = range_geom(log_c);
+        if (h_scalars) PANDA_TRY(hipStreamWaitEvent(stream, phase_events.uploaded[r], 0));
+        arena.used = sort_mark;
+        panda::SortResult sorted{};
+        const panda::SortEvents sort_events{last ? ev[1] : nullptr, last ? ev[2] : nullptr};
+        const panda::SortPlacement place{nranges > 1 ? log_n : 0u, (uint32_t)row0};
+        const void *scalars_r = (const char *)cfg.scalars + row0 * 32;
+        if (tabled)
+            PANDA_TRY(panda::msm_sort_tabled(stream, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+        else
+            PANDA_TRY(panda::msm_sort_plain(stream, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+        if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
+        if (h_scalars && !last) PANDA_TRY(upload(r + 1)); // behind this range's sort in host order, beside its kernels on the device
+        if (last) PANDA_TRY(mark(3));
+        // the first range accumulates straight into the total (zeroed: empty buckets must read as the identity); a later range into
+        // its own array, of which only the non-empty buckets are ever read, by the fix-up that adds them to the total
+        u32 *target = r == 0 ? d_bacc : d_bacc_range;
+        if (r == 0) PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
+        hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, stream, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
+                           NB, g.K, g.chunks);
+        if (last) PANDA_TRY(mark(4));
+        PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
+        if (r == 0)
+            hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+                               d_llist, g.long_cap);
+        else
+            hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+                               d_llist, g.long_cap);
+        hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, r == 0 ? 0u : 1u, NB, g.chunks, d_lcount, d_llist, g.long_cap);
+        PANDA_TRY(hipGetLastError());
+    }
     PANDA_TRY(mark(5));
     hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
     if (rowcol) {

@@ -26,6 +26,13 @@ struct SortResult {
     uint64_t stride;        // n (plain) or W*n (tabled)
 };
 
+// Where the sorted entries point.  Default ({0, 0}): at rows [0, n) of an n-row base array / of tables of n rows each.  A call that
+// runs in point-range chunks sorts 2^log_n scalars that belong to rows [row0, row0 + 2^log_n) of tables of 2^row_shift rows.
+struct SortPlacement {
+    unsigned row_shift; // 0 = default placement
+    uint32_t row0;
+};
+
 // optional events recorded on `stream` between the phases (may be null)
 struct SortEvents {
     hipEvent_t digits_done, partition_done;
@@ -34,13 +41,13 @@ struct SortEvents {
 // Plain mode: W independent lists (one per window), entries index the caller's n bases.
 size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                          SortResult *out);
+                          SortResult *out, SortPlacement place = SortPlacement{0, 0});
 
 // Tabled mode: one list over all windows; entry index = k * n + i names row i of table k (= 2^lo[k] * base i), so
 // every window falls into the same 2^(c-1) buckets and the window sums need no Horner step.
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan);
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out);
+                           SortResult *out, SortPlacement place = SortPlacement{0, 0});
 
 } // namespace panda

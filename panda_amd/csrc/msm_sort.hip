@@ -176,6 +176,7 @@ __device__ __forceinline__ void for_each_code(const Code *__restrict__ dw, u64 b
 
 struct SortGeom {
     unsigned log_n, lo_bits, H, tiles;
+    u32 row0; // plain mode: added to every point id in the final entries (the chunk's first row of the base array)
 };
 
 template <class Code>
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restr
             u32 v = pw[j];
             u32 l = v >> shift;
             u32 slot = lstart[l] + atomicAdd(&lcur[l], 1u);
-            words[slot] = (v & id_mask) | (((v >> g.log_n) & 1u) << 31);
+            words[slot] = ((v & id_mask) + g.row0) | (((v >> g.log_n) & 1u) << 31);
             lo_of[slot] = (unsigned char)l;
         }
         __syncthreads();
@@ -454,6 +455,8 @@ struct TabledGeom {
     unsigned H1, H2, S;  // 2^b1, 2^b2, W * H1
     unsigned max_tiles2; // launch bound for the level-2 tile kernels
     unsigned Q;          // H1 * H2 cells
+    unsigned row_shift;  // final entries name row (k << row_shift) + row0 + i of the concatenated tables: log2 of the rows per table
+    u32 row0;            // and the first row of the point range being sorted (both = log_n, 0 unless a call runs in point-range chunks)
 };
 
 // one workgroup: seg_tile[0..S] = exclusive prefix of ceil(len_s / SORT_TILE)
@@ -738,7 +741,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         return k;
     };
     // final word: row k*n + i of the tables, bit 31 = negate
-    auto final_word = [&](u32 v, unsigned k) -> u32 { return (v & id_mask) | (k << g.log_n) | (((v >> g.log_n) & 1u) << 31); };
+    auto final_word = [&](u32 v, unsigned k) -> u32 { return ((v & id_mask) + g.row0 + (k << g.row_shift)) | (((v >> g.log_n) & 1u) << 31); };
 
     if (N <= K3_CAP) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
@@ -813,6 +816,7 @@ SortGeom plain_geom(unsigned log_n, unsigned c)
     g.lo_bits = std::min(std::min(7u, c - 1), 31u - log_n);
     g.H = 1u << (c - 1 - g.lo_bits);
     g.tiles = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
+    g.row0 = 0;
     return g;
 }
 
@@ -835,6 +839,8 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
     g.Q = g.H1 * g.H2;
     const u64 E = (u64)plan.W << log_n;
     g.max_tiles2 = (unsigned)(E / SORT_TILE + g.S + 1);
+    g.row_shift = log_n;
+    g.row0 = 0;
     return g;
 }
 
@@ -926,13 +932,17 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
 }
 
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                          SortResult *out)
+                          SortResult *out, SortPlacement place)
 {
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
     if (c > 16 || c < 2) return hipErrorInvalidValue;
-    const SortGeom geom = plain_geom(log_n, c);
+    SortGeom geom = plain_geom(log_n, c);
     if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
+    if (place.row_shift) {
+        if ((u64)place.row0 + n > ((u64)1 << 31)) return hipErrorInvalidValue;
+        geom.row0 = place.row0;
+    }
     uint16_t *d_dig = (uint16_t *)arena.take(n * W * 2 + 16);
     u32 *d_thist = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
     u32 *d_tpref = (u32 *)arena.take((size_t)W * geom.tiles * geom.H * 4);
@@ -985,14 +995,20 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
 }
 
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out)
+                           SortResult *out, SortPlacement place)
 {
     if (!msm_sort_tabled_supported(log_n, plan)) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
     const u64 E = (u64)plan.W << log_n;
     const unsigned W = plan.W, NB = 1u << (plan.width[0] - 1);
-    const TabledGeom g = tabled_geom(log_n, plan);
+    TabledGeom g = tabled_geom(log_n, plan);
+    if (place.row_shift) { // a point range [row0, row0 + n) of tables that hold 2^row_shift rows each
+        if (place.row_shift < log_n || place.row_shift > 26 || (((u64)(W - 1) << place.row_shift) + place.row0 + n) > ((u64)1 << 31)) return hipErrorInvalidValue;
+        g.row_shift = place.row_shift;
+        g.row0 = place.row0;
+    }
     SortGeom g1;
+    g1.row0 = 0;
     g1.log_n = log_n;
     g1.lo_bits = g.b2 + g.b3;
     g1.H = g.H1;

@@ -43,12 +43,14 @@ struct PowBase {
     int has_scale;
 };
 
-// out[t] = base^t (* scale), canonical, t < count
+// out[t] = base^e(t) (* scale), canonical, t < count.  e(t) = t, or, for the two-dimensional tables of the wide inter-pass
+// twiddles (rows_deg != 0), e(t) = (t >> rows_deg) * (t & (2^rows_deg - 1)): row a holds base^(a i), i < 2^rows_deg.  e < 2^16.
 template <class Fr>
-__global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u32 *__restrict__ out)
+__global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, unsigned rows_deg, u32 *__restrict__ out)
 {
-    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const unsigned t = rows_deg ? (idx >> rows_deg) * (idx & ((1u << rows_deg) - 1)) : idx;
     Fe<Fr> acc, f;
     if (pb.has_scale) {
 #pragma unroll
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u
         }
     }
     fe_reduce_once(acc); // ONE and products are < 2p tight
-    u32 *dst = out + (size_t)t * TW_STRIDE;
+    u32 *dst = out + (size_t)idx * TW_STRIDE;
 #pragma unroll
     for (int i = 0; i < NL; i++) dst[i] = acc.l[i];
 #pragma unroll
@@ -188,11 +190,11 @@ struct PassArgs {
     const u32 *x;
     u32 *y;
     const u32 *pq;  // 2^(DEG-1) butterfly twiddles
-    const u32 *ta;  // (w^e)^t, t < 2^la
-    const u32 *tb;  // (w^(e 2^16))^t
+    const u32 *ta;  // lgp + deg <= 16: (w^e)^t, t < 2^(lgp+deg).  Wider: row k_lo holds (w^e)^(k_lo i), k_lo < 2^split
+    const u32 *tb;  // wider only: row k_hi holds (w^(e 2^split))^(k_hi i)
     unsigned log_n;
     unsigned lgp;
-    unsigned la;          // bits of m = k*i served by ta
+    unsigned split;       // 0: one lookup at k*i.  Else k = k_hi 2^split + k_lo and the twiddle is ta[k_lo][i] * tb[k_hi][i] (split = 16 - deg)
     unsigned force_tw;    // multiply by ta[0] even when m == 0 (ta carries the n^-1 factor)
     unsigned tile_elems;  // min(TILE, n)
     unsigned strided_out; // write output i of sub-transform blk to blk + i*S (the input's own layout)
@@ -241,14 +243,22 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
         load_elem(v, A.x + src_index * 8);
         if (A.lgp != 0 || A.force_tw) {
             const unsigned k = blk & (p - 1);
-            const unsigned m = k * i;
-            if (m != 0 || A.force_tw) {
+            if (k * i != 0 || A.force_tw) {
                 Fe<Fr> tw;
-                load_tw(tw, A.ta, m & ((1u << A.la) - 1));
-                if ((m >> A.la) != 0) {
-                    Fe<Fr> t2;
-                    load_tw(t2, A.tb, m >> A.la);
-                    fe_mul(tw, tw, t2);
+                if (A.split == 0)
+                    load_tw(tw, A.ta, k * i);
+                else {
+                    // exponent k*i of up to 28 bits: two lookups and a product.  Both tables are laid out [k part][i], so the four
+                    // adjacent sub-transforms of a tile read four adjacent rows of ta and ONE row of tb -- contiguous and shared with
+                    // the neighbouring tiles -- instead of 48-byte entries scattered over a 3 MB table by k*i mod 2^16 (2.2 x the
+                    // pass's input in L2 misses, profiles/r02_fetch_size_calibration.txt)
+                    const unsigned k_lo = k & ((1u << A.split) - 1), k_hi = k >> A.split;
+                    load_tw(tw, A.ta, (k_lo << DEG) | i);
+                    if (k_hi != 0) {
+                        Fe<Fr> t2;
+                        load_tw(t2, A.tb, (k_hi << DEG) | i);
+                        fe_mul(tw, tw, t2);
+                    }
                 }
                 fe_mul(v, v, tw);
             }
@@ -330,7 +340,7 @@ u32 g_omega_wire[8];
 bool g_omega_set = false;
 
 const size_t SZ_TA = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
-const size_t SZ_TB = panda::align256((size_t)(1u << 12) * TW_STRIDE * 4);
+const size_t SZ_TB = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
 const size_t SZ_PQ = panda::align256((size_t)128 * TW_STRIDE * 4);
 
 template <class Fr>
@@ -348,11 +358,11 @@ void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
 }
 
 template <class Fr>
-void build_table(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, unsigned count, u32 *d_out)
+void build_table(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, unsigned count, u32 *d_out, unsigned rows_deg = 0)
 {
     PowBase pb;
     fill_pow_base<Fr>(pb, base, scale);
-    hipLaunchKernelGGL(k_pow_table<Fr>, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, d_out);
+    hipLaunchKernelGGL(k_pow_table<Fr>, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, rows_deg, d_out);
 }
 
 template <class Fr>
@@ -390,6 +400,19 @@ struct TwiddleCache {
     int device = -1;
     bool valid = false;
     u32 key[12] = {0};
+    // tables enqueued by a call that did not wait for its stream (the *_enqueue entry points) are complete only in that
+    // stream's order: a later call on another stream waits for it first
+    hipStream_t pending = nullptr;
+    bool has_pending = false;
+    hipError_t settle(hipStream_t next)
+    {
+        if (has_pending && pending != next) {
+            hipError_t e = hipStreamSynchronize(pending);
+            if (e != hipSuccess) return e;
+        }
+        if (has_pending && pending != next) has_pending = false;
+        return hipSuccess;
+    }
     hipError_t ensure(size_t bytes)
     {
         int dev = 0;
@@ -431,7 +454,19 @@ struct TwiddleCache {
         return e;
     }
 };
-thread_local TwiddleCache g_twiddles;
+// one entry per call family, so that the alternating steps of a sharded transform do not evict each other's tables
+enum { TW_WHOLE = 0, TW_SLAB1 = 1, TW_SLAB2 = 2, TW_SLOTS = 3 };
+thread_local TwiddleCache g_twiddles[TW_SLOTS];
+
+template <class Fr>
+void twiddle_key(u32 (&key)[12], unsigned log_n, unsigned variant, const u32 *omega_wire)
+{
+    key[0] = Fr::PW[0] ^ Fr::PW[7];
+    key[1] = log_n;
+    key[2] = variant;
+    for (int i = 0; i < 8; i++) key[3 + i] = omega_wire[i];
+    key[11] = 0;
+}
 
 // All passes of one local transform of size 2^log_n with root `omega` (internal form).  `scale`, when given,
 // multiplies every output (folded into the last pass's twiddles).  Leaves the result in src when *passes_out
@@ -459,8 +494,8 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
         a.log_n = log_n;
         a.lgp = log_p;
         a.tile_elems = (unsigned)std::min<u64>(TILE, n);
-        const unsigned mbits = log_p + deg; // bits of m = k * i
-        a.la = log_p == 0 ? 16 : std::min(16u, mbits);
+        const unsigned mbits = log_p + deg; // bits of the twiddle exponent k * i
+        a.split = (log_p != 0 && mbits > 16) ? 16 - deg : 0;
         a.force_tw = (scale && last) ? 1 : 0;
         a.strided_out = 0;
         a.canonical = last ? 1 : 0;
@@ -472,11 +507,13 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
             if (log_p != 0) {
                 fe_pow_u64(base, omega, n >> log_p >> deg);
-                build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << a.la, d_ta);
-                if (mbits > 16) {
+                if (a.split == 0)
+                    build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << mbits, d_ta);
+                else {
+                    build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << 16, d_ta, deg); // [k_lo][i], k_lo < 2^split
                     Fe<Fr> base_b;
-                    fe_pow_u64(base_b, base, (u64)1 << 16);
-                    build_table<Fr>(stream, base_b, nullptr, 1u << (mbits - 16), d_tb);
+                    fe_pow_u64(base_b, base, (u64)1 << a.split);
+                    build_table<Fr>(stream, base_b, nullptr, 1u << (log_p - a.split + deg), d_tb, deg); // [k_hi][i], k_hi < 2^(log_p - split)
                 }
             } else if (a.force_tw) {
                 fe_one(base);
@@ -512,9 +549,10 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
 {
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
-    TwiddleCache &tw = g_twiddles;
-    u32 key[12] = {Fr::PW[0] ^ Fr::PW[7], log_n, inverse ? 1u : 0u, 0};
-    for (int i = 0; i < 8; i++) key[3 + i] = omega_wire[i];
+    TwiddleCache &tw = g_twiddles[TW_WHOLE];
+    u32 key[12];
+    twiddle_key<Fr>(key, log_n, inverse ? 1u : 0u, omega_wire);
+    PANDA_TRY(tw.settle(stream));
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
     const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
@@ -534,6 +572,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
     memcpy(tw.key, key, sizeof(key));
     tw.valid = true; // only after the tables are known to be complete
+    tw.has_pending = false;
     return hipSuccess;
 }
 
@@ -579,79 +618,122 @@ hipError_t ntt_coset_run(const panda_ntt_configuration_v1 &cfg, const void *shif
     return scale_by_powers<Fr>(stream, res, cfg.log_n, gi);
 }
 
-// multi-GPU step 1: local transform of the rank's decimated slab + the inter-slab twiddle w^(rank * k2)
+// shared tail of the two slab steps: publish the tables in the cache, optionally wait
+hipError_t slab_finish(TwiddleCache &tw, const u32 (&key)[12], hipStream_t stream, bool wait)
+{
+    if (wait) {
+        PANDA_TRY(hipStreamSynchronize(stream));
+        tw.has_pending = false;
+    } else {
+        tw.pending = stream;
+        tw.has_pending = true;
+    }
+    memcpy(tw.key, key, sizeof(tw.key));
+    tw.valid = true;
+    return hipSuccess;
+}
+
+// multi-GPU step 1: local transform of the rank's decimated slab + the inter-slab twiddle w^(rank * k2).
+// The twiddle tables are cached per host thread (a prover repeats the same sharded transform), so a repeat call launches only
+// the passes and the twiddle sweep and does no host-side field arithmetic.  wait = false enqueues without synchronising.
 template <class Fr>
-hipError_t slab_step1(const panda_ntt_slab_configuration &cfg)
+hipError_t slab_step1(const panda_ntt_slab_configuration &cfg, bool wait)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
+    if (cfg.rank >= (1u << cfg.log_ranks)) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     PANDA_TRY(order_after_null_stream(stream));
     const unsigned log_m = cfg.log_n - cfg.log_ranks;
     const u64 m = (u64)1 << log_m;
+    TwiddleCache &tw = g_twiddles[TW_SLAB1];
+    u32 key[12];
+    twiddle_key<Fr>(key, cfg.log_n, 0x100u | (cfg.log_ranks << 16) | (cfg.rank << 20), (const u32 *)cfg.omega);
+    PANDA_TRY(tw.settle(stream));
+    int dev = -1;
+    PANDA_TRY(hipGetDevice(&dev));
+    const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
     Fe<Fr> omega, omega_m;
-    fe_from_wire(omega, (const u32 *)cfg.omega);
-    fe_pow_u64(omega_m, omega, (u64)1 << cfg.log_ranks); // root of the local size-m transforms
-    panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    fe_zero(omega);
+    fe_zero(omega_m);
+    if (!hit) {
+        fe_from_wire(omega, (const u32 *)cfg.omega);
+        fe_pow_u64(omega_m, omega, (u64)1 << cfg.log_ranks); // root of the local size-m transforms
+        PANDA_TRY(tw.ensure(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    } else
+        tw.used = 0;
+    tw.valid = false;
     unsigned passes = 0;
-    PANDA_TRY(ntt_passes<Fr>(stream, arena, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes));
+    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes, !hit));
     u32 *res = (passes & 1u) ? (u32 *)cfg.d_scratch : (u32 *)cfg.d_slab;
     if (cfg.rank != 0) {
-        u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB);
+        u32 *d_ta = (u32 *)tw.take(SZ_TA), *d_tb = (u32 *)tw.take(SZ_TB);
         if (!d_ta || !d_tb) return hipErrorOutOfMemory;
-        Fe<Fr> base, base_b;
-        fe_pow_u64(base, omega, cfg.rank);
-        build_table<Fr>(stream, base, nullptr, (unsigned)std::min<u64>(m, 1u << 16), d_ta);
-        if (log_m > 16) {
-            fe_pow_u64(base_b, base, (u64)1 << 16);
-            build_table<Fr>(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
+        if (!hit) {
+            Fe<Fr> base, base_b;
+            fe_pow_u64(base, omega, cfg.rank);
+            build_table<Fr>(stream, base, nullptr, (unsigned)std::min<u64>(m, 1u << 16), d_ta);
+            if (log_m > 16) {
+                fe_pow_u64(base_b, base, (u64)1 << 16);
+                build_table<Fr>(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
+            }
         }
         hipLaunchKernelGGL(k_slab_twiddle<Fr>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, res, d_ta, d_tb, (unsigned)m);
         PANDA_TRY(hipGetLastError());
     }
-    if (cfg.flag) *(unsigned *)cfg.flag = passes & 1u;
-    PANDA_TRY(hipStreamSynchronize(stream));
-    return hipSuccess;
+    if (cfg.flag) *(unsigned *)cfg.flag = passes & 1u; // known without waiting: the parity of the pass count
+    return slab_finish(tw, key, stream, wait);
 }
 
 // multi-GPU step 2: after the all-to-all the slab holds [j1][k2'] (G x m/G); transforms of size G down j1
 template <class Fr>
-hipError_t slab_step2(const panda_ntt_slab_configuration &cfg)
+hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < 2 * cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     PANDA_TRY(order_after_null_stream(stream));
     const unsigned log_m = cfg.log_n - cfg.log_ranks;
     const u64 m = (u64)1 << log_m;
-    unsigned out_in_scratch = 0;
-    if (cfg.log_ranks != 0) {
+    if (cfg.log_ranks == 0) {
+        if (cfg.flag) *(unsigned *)cfg.flag = 0;
+        if (wait) PANDA_TRY(hipStreamSynchronize(stream));
+        return hipSuccess;
+    }
+    TwiddleCache &tw = g_twiddles[TW_SLAB2];
+    u32 key[12];
+    twiddle_key<Fr>(key, cfg.log_n, 0x200u | (cfg.log_ranks << 16), (const u32 *)cfg.omega);
+    PANDA_TRY(tw.settle(stream));
+    int dev = -1;
+    PANDA_TRY(hipGetDevice(&dev));
+    const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
+    if (!hit)
+        PANDA_TRY(tw.ensure(SZ_PQ + 4096));
+    else
+        tw.used = 0;
+    tw.valid = false;
+    u32 *d_pq = (u32 *)tw.take(SZ_PQ);
+    if (!d_pq) return hipErrorOutOfMemory;
+    if (!hit) {
         Fe<Fr> omega, base;
         fe_from_wire(omega, (const u32 *)cfg.omega);
-        panda::Arena &arena = panda::thread_arena();
-        PANDA_TRY(arena.reserve(SZ_TA + SZ_TB + SZ_PQ + 4096));
-        u32 *d_pq = (u32 *)arena.take(SZ_PQ);
-        if (!d_pq) return hipErrorOutOfMemory;
         fe_pow_u64(base, omega, m); // w^m has order G
         build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
-        PassArgs a{};
-        a.x = (const u32 *)cfg.d_slab;
-        a.y = (u32 *)cfg.d_scratch;
-        a.pq = d_pq;
-        a.ta = a.tb = d_pq;
-        a.log_n = log_m;
-        a.lgp = 0;
-        a.la = 16;
-        a.force_tw = 0;
-        a.tile_elems = (unsigned)std::min<u64>(TILE, m);
-        a.strided_out = 1;
-        a.canonical = 1;
-        launch_pass<Fr>(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
-        PANDA_TRY(hipGetLastError());
-        out_in_scratch = 1;
     }
-    if (cfg.flag) *(unsigned *)cfg.flag = out_in_scratch;
-    PANDA_TRY(hipStreamSynchronize(stream));
-    return hipSuccess;
+    PassArgs a{};
+    a.x = (const u32 *)cfg.d_slab;
+    a.y = (u32 *)cfg.d_scratch;
+    a.pq = d_pq;
+    a.ta = a.tb = d_pq;
+    a.log_n = log_m;
+    a.lgp = 0;
+    a.split = 0;
+    a.force_tw = 0;
+    a.tile_elems = (unsigned)std::min<u64>(TILE, m);
+    a.strided_out = 1;
+    a.canonical = 1;
+    launch_pass<Fr>(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
+    PANDA_TRY(hipGetLastError());
+    if (cfg.flag) *(unsigned *)cfg.flag = 1;
+    return slab_finish(tw, key, stream, wait);
 }
 
 } // namespace
@@ -705,9 +787,16 @@ panda_error panda_ntt_execute_bn254_inverse_bitrev_in(const panda_ntt_configurat
         ntt_run<Bn254Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true, true, false));
 }
 
-panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg)); }
+panda_error panda_ntt_slab_step1_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg, true)); }
 
-panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg)); }
+panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg, true)); }
+
+// The same two steps without the wait at the end: everything is enqueued on cfg.stream and *flag is written before the call returns
+// (it is the parity of the pass count), so a caller that issues the all-to-all on the same stream composes
+// step 1 -> exchange -> step 2 with a single synchronisation at the end instead of three.
+panda_error panda_ntt_slab_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg, false)); }
+
+panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg, false)); }
 
 panda_error panda_ntt_execute_bn254_coset(const panda_ntt_configuration_v1 cfg, const void *shift)
 {
@@ -749,7 +838,7 @@ panda_error panda_ntt_tear_down(void)
 {
     std::lock_guard<std::mutex> lock(g_omega_mutex);
     g_omega_set = false;
-    (void)g_twiddles.release();
+    for (auto &t : g_twiddles) (void)t.release();
     return static_cast<panda_error>(panda::release_thread_arena());
 }
 

@@ -120,6 +120,33 @@ int main()
         printf("Run k = %u, compare successfully\n", k);
     }
 
+    { // the upload / execute pipeline inside one with_cached_bases call (2^19 points: two ranges), tables and converted-only bases,
+      // against the staged call over the same inputs
+        const unsigned k = 19;
+        const size_t n = (size_t)1 << k;
+        REQUIRE(pipeline_ranges(k) == 2);
+        std::vector<uint8_t> bases(n * 64), scalars(n * 32);
+        void *d = nullptr;
+        REQUIRE(panda_malloc(&d, n * 64) == 0);
+        REQUIRE(panda_gen_bases(0, 1000 + k, 0, n, d, gm.get_exec_stream()) == 0);
+        REQUIRE(panda_memcpy(bases.data(), d, n * 64) == 0);
+        REQUIRE(panda_gen_scalars(0, 2000 + k, 0, n, d, gm.get_exec_stream()) == 0);
+        REQUIRE(panda_memcpy(scalars.data(), d, n * 32) == 0);
+        REQUIRE(panda_free(d) == 0);
+        std::vector<uint8_t> staged, piped;
+        REQUIRE(panda_msm_bn254_gpu(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &staged) == PandaGpuError::Ok);
+        for (int tables = 0; tables < 2; tables++) {
+            void *db = nullptr;
+            REQUIRE(PandaGpuManager::init_msm_cached_bases(Bytes{bases.data(), bases.size()}, &db) == PandaGpuError::Ok);
+            gm.d_bases.push_back(db);
+            const size_t bi = gm.d_bases.size() - 1;
+            REQUIRE((tables ? gm.precompute_cached_bases(bi, k) : gm.register_cached_bases(bi, k)) == PandaGpuError::Ok);
+            REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, bi, &piped) == PandaGpuError::Ok);
+            REQUIRE(affine_of(piped, false) == affine_of(staged, false));
+        }
+        printf("Run k = %u through the single-call pipeline, compare successfully\n", k);
+    }
+
     for (unsigned log_n : {4u, 10u, 17u}) { // NTT: v1 forward, global-omega forward, inverse
         const size_t n = (size_t)1 << log_n;
         std::vector<uint8_t> x(n * 32);

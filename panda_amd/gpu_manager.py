@@ -276,15 +276,41 @@ def panda_msm_bn254_gpu(gm: PandaGpuManager, scalars, bases, curve: int = BN254)
     return _msm_device(gm, d_scalars, d_bases, log_2(s.size // FIELD_ELEMENT_LEN), curve, True, True)
 
 
+def pipeline_chunks(log_n: int) -> int:
+    """Point ranges a single call's upload / execute pipeline is cut into: n/2^(R-1), n/2^(R-1), n/2^(R-2), ..., n/2 points (the
+    library lowers R until the first range holds 2^16 points)."""
+    return 5 if log_n >= 24 else (4 if log_n >= 22 else (3 if log_n >= 20 else (2 if log_n >= 18 else 1)))
+
+
 def panda_msm_bn254_gpu_with_cached_bases(gm: PandaGpuManager, scalars, bases_index: int, curve: int = BN254) -> np.ndarray:
-    """unit.rs:103-188."""
+    """unit.rs:103-188.  When the cached base set is registered with the library (register_cached_bases /
+    precompute_cached_bases) the upload and the execution are pipelined inside the one call: the scalars cross
+    PCIe range by range on the h2d stream while the previous range is already being accumulated on the exec stream
+    (panda_msm_execute_from_host); otherwise the reference's order -- upload everything, then execute."""
     s = _as_bytes(scalars)
-    d_scalars = memory_alloc_and_copy(gm, s, gm.h2d_stream)
-    gm.wait_h2d()
     d_bases = gm.get_params_bases_ptr_mut(bases_index)
     if d_bases is None:
         raise PandaGpuError("BasesIndexErr")
-    return _msm_device(gm, d_scalars, d_bases, log_2(s.size // FIELD_ELEMENT_LEN), curve, True, False)
+    log_n = log_2(s.size // FIELD_ELEMENT_LEN)
+    chunks = pipeline_chunks(log_n)
+    if d_bases in gm._registered and chunks > 1:
+        lib = ffi.load()
+        nres = _RESULT_BYTES[curve]
+        d_scalars = _pool_alloc(gm, (1 << log_n) * FIELD_ELEMENT_LEN, gm.h2d_stream)
+        d_result = _pool_alloc(gm, nres, gm.h2d_stream)
+        gm.wait_h2d()
+        cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d_bases, d_scalars, d_result, log_n, gm.msm_result_coordinate_type)
+        try:
+            ffi.check(lib.panda_msm_execute_from_host(curve, cfg, _ptr(s), chunks, gm.h2d_stream.raw), "SchedulingErr")
+            out = np.zeros(nres, dtype=np.uint8)
+            ffi.check(lib.panda_memcpy(_ptr(out), C.c_void_p(d_result), nres), "CreateContextError")
+        finally:
+            lib.panda_free(C.c_void_p(d_scalars))
+            lib.panda_free(C.c_void_p(d_result))
+        return out
+    d_scalars = memory_alloc_and_copy(gm, s, gm.h2d_stream)
+    gm.wait_h2d()
+    return _msm_device(gm, d_scalars, d_bases, log_n, curve, True, False)
 
 
 def panda_msm_bn254_gpu_with_cached_bases_batched(gm: PandaGpuManager, scalars_batches, bases_index: int, curve: int = BN254) -> list:

@@ -91,13 +91,17 @@ def all_to_all_slab(tensor, group=None):
     return out
 
 
-def _slab_step(step: int, pstream, d_slab: int, d_scratch: int, omega: np.ndarray, log_n: int, log_ranks: int, rank: int) -> int:
-    """One device half of the sharded transform through the C ABI; returns the flag (1: the output sits in d_scratch)."""
+def _slab_step(step: int, pstream, d_slab: int, d_scratch: int, omega: np.ndarray, log_n: int, log_ranks: int, rank: int, wait: bool = True) -> int:
+    """One device half of the sharded transform through the C ABI; returns the flag (1: the output sits in d_scratch).
+    wait=False uses the *_enqueue entry points: nothing is synchronised, the work is ordered on `pstream`."""
     lib = ffi.load()
     flag = C.c_uint(7)
     cfg = ffi.NttSlabConfiguration(pstream, C.c_void_p(d_slab), C.c_void_p(d_scratch), C.c_void_p(omega.ctypes.data), log_n, log_ranks, rank,
                                    C.pointer(flag))
-    fn = lib.panda_ntt_slab_step1_bn254 if step == 1 else lib.panda_ntt_slab_step2_bn254
+    if wait:
+        fn = lib.panda_ntt_slab_step1_bn254 if step == 1 else lib.panda_ntt_slab_step2_bn254
+    else:
+        fn = lib.panda_ntt_slab_step1_bn254_enqueue if step == 1 else lib.panda_ntt_slab_step2_bn254_enqueue
     ffi.check(fn(cfg), "SchedulingErr")
     assert flag.value in (0, 1)
     return flag.value
@@ -131,16 +135,18 @@ def ntt_sharded(slab, scratch, omega, log_n: int, group=None, stream=None):
     s = stream if stream is not None else torch.cuda.current_stream(slab.device)
     pstream = ffi.PandaStream(s.cuda_stream)
     with torch.cuda.stream(s):
-        flag = _slab_step(1, pstream, slab.data_ptr(), scratch.data_ptr(), om, log_n, g, rank)
+        # everything is enqueued on `s`: step 1 does not wait (its flag is the parity of the pass count), the collective is ordered
+        # after it by torch, step 2 follows on the same stream; one synchronisation at the end
+        flag = _slab_step(1, pstream, slab.data_ptr(), scratch.data_ptr(), om, log_n, g, rank, wait=False)
         src, dst = (scratch, slab) if flag else (slab, scratch)
         if dist.get_backend(group) == "nccl":
             dist.all_to_all_single(dst, src, group=group)  # chunk q of every rank -> rank q; each GPU pair has its own xGMI link
         else:
             recv = torch.empty(src.numel(), dtype=torch.uint8)
-            dist.all_to_all_single(recv, src.cpu(), group=group)
+            dist.all_to_all_single(recv, src.cpu(), group=group)  # .cpu() waits for step 1 on this stream
             dst.copy_(recv)
-            s.synchronize()
-        flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, rank)
+        flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, rank, wait=False)
+        s.synchronize()
     return src if flag else dst
 
 

@@ -862,6 +862,73 @@ def test_msm_batched_pipeline_over_cached_bases(gm, tabled):
         pgm.panda_msm_bn254_gpu_with_cached_bases_batched(gm, batches[:1], 999)
 
 
+@pytest.mark.parametrize("cid,k,tabled,chunks,source", [(0, 17, True, 2, "pageable"), (0, 19, True, 8, "pinned"), (0, 19, False, 4, "pinned"), (0, 20, True, 4, "resident"),
+                                                         (1, 18, True, 4, "pageable"), (0, 18, True, 64, "pinned"), (0, 15, True, 4, "pinned"), (0, 18, None, 4, "pinned")])
+def test_msm_upload_pipeline_inside_one_call(gm, cid, k, tabled, chunks, source):
+    """panda_msm_execute_from_host cuts one MSM into point ranges, uploads range r+1 while range r is accumulated against
+    its own rows of the registered tables, merges the ranges' buckets on the device.  Same group element as the ordinary call, for
+    tables / converted-only / unregistered bases (the last falls back to copy-then-execute), pageable, pinned and resident scalars,
+    range counts the library has to clamp (64 ranges of 2^18 points, 4 ranges of 2^15), and skewed scalars."""
+    lib = ffi.load()
+    n = 1 << k
+    lc = po.LC_Q[cid]
+    seed_b, seed_s = 0x70616E6461 ^ (0xF200 + 16 * k + cid), 0xF2F2 + k
+    db, ds, dr = DeviceBuffer(n * 2 * lc * 4), DeviceBuffer(n * 32), DeviceBuffer(3 * lc * 4)
+    ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(cid, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scalars = ds.to_host().reshape(n, 8)
+    scalars[n // 3:n // 3 + 3000] = scalars[5]  # a run of equal scalars: one bucket per window takes thousands of entries in one range
+    scalars[::7] = 0
+    want = po.expected_from_linearity(cid, seed_b, scalars)
+    if tabled is True:
+        ffi.check(lib.panda_msm_precompute_bases(cid, db.ptr, k, 0, gm.exec_stream.raw), "precompute")
+    elif tabled is False:
+        ffi.check(lib.panda_msm_register_bases(cid, db.ptr, k, gm.exec_stream.raw), "register")
+    pinned = C.c_void_p()
+    if source == "pinned":
+        ffi.check(lib.panda_malloc_host(C.byref(pinned), n * 32), "malloc_host")
+        C.memmove(pinned, scalars.ctypes.data, n * 32)
+        h_ptr = pinned
+        ffi.check(lib.panda_memset(ds.ptr, 0xEE, n * 32), "memset")  # the device buffer holds nothing useful before the call
+    elif source == "pageable":
+        h_ptr = C.c_void_p(scalars.ctypes.data)
+        ffi.check(lib.panda_memset(ds.ptr, 0xEE, n * 32), "memset")
+    else:
+        h_ptr = None
+        ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(scalars.ctypes.data), n * 32), "memcpy")
+    for coord in (pgm.JACOBIAN, pgm.PROJECTIVE):
+        cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, coord)
+        ffi.check(lib.panda_msm_execute_from_host(cid, cfg, h_ptr, chunks, gm.h2d_stream.raw), "msm")
+        got = dr.to_host()
+        assert ((po.hom_to_affine(cid, got) if coord == pgm.PROJECTIVE else po.to_affine(cid, got)) == want).all()
+    assert (ds.to_host().reshape(n, 8) == scalars).all()  # the whole scalar set arrived on the device
+    if tabled is not None:
+        ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
+    if pinned:
+        lib.panda_free_host(pinned)
+    for d in (db, ds, dr):
+        d.free()
+
+
+def test_msm_upload_pipeline_through_the_manager(gm):
+    """panda_msm_bn254_gpu_with_cached_bases over a registered base set takes the pipelined path (2^19 points: two ranges)."""
+    k = 19
+    n = 1 << k
+    lib = ffi.load()
+    db = DeviceBuffer(n * 64)
+    ffi.check(lib.panda_gen_bases(0, 0xF3, 0, n, db.ptr, NULL_STREAM), "gen")  # the oracle's generator takes too long for 2^19 points
+    bases = db.to_host().reshape(n, 16)
+    db.free()
+    scalars = po.gen_scalars(po.F_BN254_FR, 0xF4, n)
+    idx = gm.add_cached_bases(bases)
+    gm.precompute_cached_bases(idx)
+    assert pgm.pipeline_chunks(k) == 2
+    keep = scalars.copy()
+    out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx)
+    assert (affine_of(0, out) == po.expected_from_linearity(0, 0xF3, scalars)).all()
+    assert (scalars == keep).all()
+
+
 def test_msm_ragged_lengths_and_bad_arguments(gm):
     """unit.rs:31: n = 2^floor(log2(len / 32)) -- a ragged scalar slice uses its leading power-of-two prefix (and as many bases).
     Null pointers and oversize counts come back as panda_error_invalid_value, never as a crash."""
