@@ -1,0 +1,172 @@
+// ubench_batchaffine.hip -- would batched-affine accumulation beat the XYZZ mixed addition of k_accumulate?  
+// Measures, on the same fe29 arithmetic and at k_accumulate's occupancy (128-thread blocks, 4 waves per SIMD):
+//   xyzz      acc += P_j, XYZZ mixed addition (8M + 2S, one fused reduction): what k_accumulate does per sorted entry
+//   affine*   the affine addition with the inverse GIVEN (lambda = (y2-y1) * inv, x3 = lambda^2 - x1 - x2, y3 = lambda (x1-x3) - y1:
+//             2M + 1S) plus the three multiplications per element of Montgomery's simultaneous inversion (prefix product, and
+//             two to unwind) = 5M + 1S: the floor of ANY batched-affine scheme, with the shared inversion itself costing nothing
+//   affine C  the complete per-lane scheme: C independent accumulators per lane (registers), one Fermat inversion per lane and
+//             step shared by its C additions -- the only arrangement that needs no cross-lane traffic
+//   inverse   one Fermat inversion per lane (a^(p-2), what fe_inv does): its cost in additions is what a batch has to amortise
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipanda_amd/csrc -o gpurun_out/ubench_batchaffine tools/ubench_batchaffine.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "curve29.h"
+
+using namespace panda29;
+typedef Bn254Fq F;
+constexpr int STEPS = 64;
+
+template <class T>
+__device__ __forceinline__ void sink(u32 *out, const T &v, unsigned t)
+{
+    u32 s = 0;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) s ^= v.l[i];
+    out[t] = s;
+}
+
+__device__ __forceinline__ void load_pt(Fe<F> &x, Fe<F> &y, const u32 *pts, unsigned idx)
+{
+    const u32 *p = pts + (size_t)(idx & 4095) * 2 * F::N; // 4096 points of 72 bytes: L2-resident, no HBM effects
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+        x.l[i] = p[i];
+        y.l[i] = p[F::N + i];
+    }
+}
+
+__global__ void __launch_bounds__(128, 4) k_xyzz(const u32 *__restrict__ pts, u32 *__restrict__ out)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    Xyzz<F> acc;
+    Fe<F> x, y;
+    load_pt(x, y, pts, t);
+    xyzz_from_affine(acc, x, y);
+    for (int j = 1; j <= STEPS; j++) {
+        load_pt(x, y, pts, t * 31 + j * 977);
+        (void)xyzz_madd_core(acc, x, y);
+    }
+    sink(out, acc.X, t);
+}
+
+// affine addition, inverse of (x2 - x1) given
+__device__ __forceinline__ void affine_add(Fe<F> &x1, Fe<F> &y1, const Fe<F> &x2, const Fe<F> &y2, const Fe<F> &inv)
+{
+    Fe<F> dy, lam, l2, t, x3, y3;
+    fe_sub<F, 2>(dy, y2, y1);
+    fe_mul(lam, dy, inv);
+    fe_sqr(l2, lam);
+    fe_sub<F, 2>(t, l2, x1);
+    fe_sub<F, 2>(x3, t, x2);
+    fe_sub<F, 2>(t, x1, x3);
+    fe_mul(y3, lam, t);
+    fe_sub<F, 2>(y3, y3, y1);
+    fe_reduce_small_2p(x3);
+    fe_reduce_small_2p(y3);
+    x1 = x3;
+    y1 = y3;
+}
+
+// C accumulators per lane, one shared inversion per step.  FREE_INV: the inversion is replaced by a copy (floor of the scheme)
+template <int C, bool FREE_INV>
+__global__ void __launch_bounds__(128, (C <= 2 ? 4 : 2)) k_affine(const u32 *__restrict__ pts, u32 *__restrict__ out)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<F> ax[C], ay[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) load_pt(ax[c], ay[c], pts, t * C + c);
+    for (int j = 1; j <= STEPS / C; j++) {
+        Fe<F> bx[C], by[C], d[C], pre[C], inv, di;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            load_pt(bx[c], by[c], pts, (t * C + c) * 31 + j * 977);
+            fe_sub<F, 2>(d[c], bx[c], ax[c]);
+            fe_reduce_small_2p(d[c]);
+            if (c == 0)
+                pre[0] = d[0];
+            else
+                fe_mul(pre[c], pre[c - 1], d[c]); // prefix products
+        }
+        if (FREE_INV)
+            inv = pre[C - 1];
+        else
+            fe_inv(inv, pre[C - 1]);
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+            if (c > 0) {
+                fe_mul(di, inv, pre[c - 1]); // 1 / d[c]
+                fe_mul(inv, inv, d[c]);      // inverse of the remaining prefix
+            } else
+                di = inv;
+            affine_add(ax[c], ay[c], bx[c], by[c], di);
+        }
+    }
+    Fe<F> s = ax[0];
+#pragma unroll
+    for (int c = 1; c < C; c++) fe_add(s, s, ay[c]);
+    sink(out, s, t);
+}
+
+__global__ void __launch_bounds__(128, 4) k_inverse(const u32 *__restrict__ pts, u32 *__restrict__ out)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<F> x, y, r;
+    load_pt(x, y, pts, t);
+    fe_inv(r, x);
+    fe_inv(y, r);
+    sink(out, y, t);
+}
+
+template <class Fn>
+static float time_ms(Fn launch)
+{
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    launch();
+    (void)hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int r = 0; r < 3; r++) {
+        (void)hipEventRecord(a, 0);
+        launch();
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        best = ms < best ? ms : best;
+    }
+    return best;
+}
+
+int main()
+{
+    const unsigned threads = 1u << 21; // 8 rounds of the chip at four waves per SIMD
+    u32 *pts = nullptr, *out = nullptr;
+    if (hipMalloc(&pts, 4096 * 2 * F::N * 4) != hipSuccess || hipMalloc(&out, (size_t)threads * 4) != hipSuccess) return 1;
+    {
+        u32 h[4096 * 2 * F::N];
+        unsigned long long s = 88172645463325252ull;
+        for (auto &v : h) {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            v = (u32)s & 0x0fffffffu; // 28-bit limbs: residues below p, arbitrary "points" (timing only; exceptional cases cannot hit)
+        }
+        (void)hipMemcpy(pts, h, sizeof(h), hipMemcpyHostToDevice);
+    }
+    const double adds = (double)threads * STEPS;
+    const float t_x = time_ms([&] { hipLaunchKernelGGL(k_xyzz, dim3(threads / 128), dim3(128), 0, 0, pts, out); });
+    printf("variant,ms,G additions/s,time per addition relative to XYZZ\n");
+    printf("xyzz mixed addition (k_accumulate's),%.3f,%.2f,1.000\n", t_x, adds / t_x / 1e6);
+    auto row = [&](const char *name, float ms, double n_adds) { printf("%s,%.3f,%.2f,%.3f\n", name, ms, n_adds / ms / 1e6, (ms / n_adds) / (t_x / adds)); };
+    row("affine 5M+1S with a free inverse; 1 accumulator per lane", time_ms([&] { hipLaunchKernelGGL((k_affine<1, true>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    row("affine 5M+1S with a free inverse; 4 accumulators per lane", time_ms([&] { hipLaunchKernelGGL((k_affine<4, true>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    row("affine 5M+1S with a free inverse; 8 accumulators per lane", time_ms([&] { hipLaunchKernelGGL((k_affine<8, true>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    row("affine; per-lane Fermat inversion shared by 4 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<4, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    row("affine; per-lane Fermat inversion shared by 8 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<8, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    row("affine; per-lane Fermat inversion shared by 16 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<16, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    const float t_i = time_ms([&] { hipLaunchKernelGGL(k_inverse, dim3(threads / 128), dim3(128), 0, 0, pts, out); });
+    printf("one Fermat inversion per lane,%.3f,%.3f G inversions/s,= %.1f XYZZ additions\n", t_i / 2, (double)threads * 2 / t_i / 1e6, (t_i / 2 / threads) / (t_x / adds));
+    return 0;
+}
