@@ -18,7 +18,7 @@
 // The wire format stays the reference's (Montgomery form with R_wire = 2^(32 L), 32-bit limbs,
 // field_storage.cuh:12-16); fe_from_wire / fe_to_wire convert with one extra multiply.
 //
-// Bounds contract (N = 9 figures; checked exhaustively by tests/host_check/fe29_check.cpp):
+// Bounds contract (N = 9 figures; checked exhaustively by tests/host_check/fe29_host.cpp through tests/test_fe29_host.py):
 //   limb classes   tight : limbs 0..N-2 <  2^29             (outputs of fe_mul / fe_sqr / fe_unpack)
 //                  loose : limbs 0..N-2 <= 2^29 + 8         (outputs of fe_norm / fe_sub / fe_add)
 //                  raw   : limbs 0..N-2 <  2^30 + 16        (fe_add_nr of two loose values)

@@ -237,7 +237,14 @@ struct PackedBase {
 template <class F>
 __device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
 {
+#if defined(ACC_EXPERIMENT) && (ACC_EXPERIMENT & 1) // timing experiment only (wrong results): every gather stays inside a small region
+#ifndef ACC_EXPERIMENT_MASK
+#define ACC_EXPERIMENT_MASK 0xfffu
+#endif
+    load_words<2 * F::L>(b.w, bases + (u64)(entry & ACC_EXPERIMENT_MASK) * 2 * F::L);
+#else
     load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
+#endif
 }
 
 // RAW: a negated y comes back un-normalised (limbs < 2^31) -- good enough for the one product it feeds in
@@ -252,7 +259,11 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
     inf = (nz == 0);
     fe_unpack(x, b.w);
     fe_unpack(y, b.w + L);
+#if defined(ACC_EXPERIMENT) && (ACC_EXPERIMENT & 2) // timing experiment only: no conditional negation
+    if (false) {
+#else
     if (entry >> 31) {
+#endif
         Fe<F> ny;
         if constexpr (RAW)
             fe_neg_raw<F, 1>(ny, y); // y is canonical (< p)
@@ -289,12 +300,16 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
 
     u32 b = owner_bucket(ow, NB, start);
     u32 next = ow[b + 1];
+    bool run_starts_inside = ow[b] >= start; // only the first run of a chunk can have begun in an earlier chunk
     Xyzz<F> acc;
     xyzz_set_identity(acc);
 
     // Software pipeline: while the addition of entry `pos` runs, the base of entry pos+1 (still packed: 16 registers)
     // and the sorted word of entry pos+2 are in flight, so neither the gather nor the dependent address load is waited
-    // for at its point of issue.
+    // for at its point of issue.  The run-boundary work sits BEFORE the gather is issued: its dependent load of the next
+    // boundary waits on everything outstanding (the counter is in order), and with the fresh gather among it a wave --
+    // which meets a boundary in one iteration out of two -- stalled for an HBM round trip each time (k_accumulate ran
+    // 14.5 ms with the rows in HBM against 12.2 ms with L2-resident rows: profiles/r02_accumulate_stalls.txt).
     PackedBase<F> next_base;
     u32 cur_entry = sw[start];
     u32 ahead_entry = start + 1 < end ? sw[start + 1] : 0u;
@@ -304,14 +319,10 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
         bool cinf;
         const u32 entry = cur_entry;
         unpack_base<F, ACC_RAW_Y && RawOperandOk<F>::value>(cx, cy, cinf, next_base, entry);
-        if (pos + 1 < end) {
-            cur_entry = ahead_entry;
-            fetch_base<F>(next_base, bases, cur_entry);
-            if (pos + 2 < end) ahead_entry = sw[pos + 2];
-        }
-        if (pos >= next) { // the run of bucket b ends here; this entry opens the next run, so it simply becomes the accumulator
-            const bool complete = ow[b] >= start; // its end (== pos) is inside the chunk by construction
-            store_xyzz<F>(complete ? bw + (u64)b * PW : pw, acc);
+        const bool boundary = pos >= next;
+        if (boundary) { // the run of bucket b ends here; this entry opens the next run, so it simply becomes the accumulator
+            store_xyzz<F>(run_starts_inside ? bw + (u64)b * PW : pw, acc); // its end (== pos) is inside the chunk by construction
+            run_starts_inside = true;
             do {
                 b++;
                 next = ow[b + 1];
@@ -323,8 +334,13 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
                 fe_norm(ty, cy);
                 xyzz_from_affine(acc, cx, ty);
             }
-            continue;
         }
+        if (pos + 1 < end) {
+            cur_entry = ahead_entry;
+            fetch_base<F>(next_base, bases, cur_entry);
+            if (pos + 2 < end) ahead_entry = sw[pos + 2];
+        }
+        if (boundary) continue;
         if (cinf) continue;
         if (xyzz_is_identity(acc)) {
             Fe<F> ty;
@@ -344,7 +360,7 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
         }
     }
     // last run: complete only if the bucket both starts and ends inside the chunk
-    const bool starts_inside = ow[b] >= start;
+    const bool starts_inside = run_starts_inside;
     const bool ends_inside = next <= end;
     u32 *dst = (starts_inside && ends_inside) ? bw + (u64)b * PW : (starts_inside ? pw + PW : pw);
     store_xyzz<F>(dst, acc);

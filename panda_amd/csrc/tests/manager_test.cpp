@@ -4,6 +4,8 @@
 // NTT forward/inverse round trip.  Independent parity against the oracle lives in tests/test_gpu_parity.py.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "../curve29.h"
@@ -68,10 +70,58 @@ static void root_of_unity(u32 *omega_wire, unsigned log_n)
     fe_to_wire(omega_wire, acc);
 }
 
-int main()
+static bool read_file(const std::string &path, std::vector<uint8_t> *out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize((size_t)len);
+    const bool ok = fread(out->data(), 1, (size_t)len, f) == (size_t)len;
+    fclose(f);
+    return ok;
+}
+
+int main(int argc, char **argv)
 {
     PandaGpuManager gm;
     REQUIRE(PandaGpuManager::create(0, &gm) == PandaGpuError::Ok);
+
+    { // known answer: the reference's own fixture (src/cuda/test/data/msm/k13: 8192 x the generator (1, 2), every addition a P + P;
+      // scalars and the affine result are kept as data under tests/golden/).  Device path, CPU entry point and the table path must
+      // all reproduce the 64 bytes the reference's test dumped -- a comparison that does not go through this library twice.
+        std::string exe = argc > 0 ? argv[0] : "";
+        const size_t cut = exe.rfind("panda_amd/csrc/tests/");
+        const std::string golden = (cut == std::string::npos ? std::string("../../../") : exe.substr(0, cut)) + "tests/golden/";
+        std::vector<uint8_t> scalars, want;
+        if (read_file(golden + "ref_k13_scalars.bin", &scalars) && read_file(golden + "ref_k13_result_affine.bin", &want)) {
+            REQUIRE(scalars.size() == 8192 * 32 && want.size() == 64);
+            std::vector<uint8_t> bases(8192 * 64, 0), gpu, cpu, tab;
+            u32 one[8], two[8];
+            Fe<Bn254Fq> e;
+            fe_from_u32(e, 1);
+            fe_to_wire(one, e);
+            fe_from_u32(e, 2);
+            fe_to_wire(two, e);
+            for (size_t i = 0; i < 8192; i++) {
+                memcpy(bases.data() + i * 64, one, 32);
+                memcpy(bases.data() + i * 64 + 32, two, 32);
+            }
+            REQUIRE(panda_msm_bn254_gpu(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &gpu) == PandaGpuError::Ok);
+            REQUIRE(affine_of(gpu, false) == want);
+            REQUIRE(panda_msm_bn254_gpu_host(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &cpu) == PandaGpuError::Ok);
+            REQUIRE(affine_of(cpu, false) == want);
+            void *db = nullptr;
+            REQUIRE(PandaGpuManager::init_msm_cached_bases(Bytes{bases.data(), bases.size()}, &db) == PandaGpuError::Ok);
+            gm.d_bases.push_back(db);
+            REQUIRE(gm.precompute_cached_bases(gm.d_bases.size() - 1, 13) == PandaGpuError::Ok);
+            REQUIRE(panda_msm_bn254_gpu_with_cached_bases(gm, Bytes{scalars.data(), scalars.size()}, gm.d_bases.size() - 1, &tab) == PandaGpuError::Ok);
+            REQUIRE(affine_of(tab, false) == want);
+            printf("Reference k13 golden vector reproduced by the device path, the CPU entry point and the table path\n");
+        } else
+            printf("tests/golden not found next to the binary: k13 known-answer check skipped\n");
+    }
 
     for (unsigned k : {10u, 12u, 14u, 16u}) { // test_msm_bn254_correctness_device
         const size_t n = (size_t)1 << k;

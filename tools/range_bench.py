@@ -11,6 +11,8 @@ import torch  # noqa: E402
 
 from panda_amd import gpu_ffi as ffi  # noqa: E402
 
+if os.environ.get("PANDA_LIB"):  # timing experiments: another build of the library
+    ffi.LIB_PATH = os.environ["PANDA_LIB"]
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n = 1 << log_n
 lib = ffi.load()
@@ -25,7 +27,7 @@ ffi.check(lib.panda_gen_scalars(0, 2, 0, n, scalars.data_ptr(), ps), "gen")
 ffi.check(lib.panda_msm_precompute_bases(0, bases.data_ptr(), log_n, 0, ps), "pre")
 cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ps, bases.data_ptr(), scalars.data_ptr(), result.data_ptr(), log_n, 0)
 ref = None
-for R in (1, 2, 3, 4, 5, 6):
+for R in ([1] if os.environ.get("PANDA_LIB") else [1, 2, 3, 4, 5, 6]):
     best = 1e9
     for _ in range(4):
         torch.cuda.synchronize()

@@ -166,6 +166,10 @@ int main()
     row("affine; per-lane Fermat inversion shared by 4 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<4, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
     row("affine; per-lane Fermat inversion shared by 8 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<8, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
     row("affine; per-lane Fermat inversion shared by 16 additions", time_ms([&] { hipLaunchKernelGGL((k_affine<16, false>), dim3(threads / 128), dim3(128), 0, 0, pts, out); }), adds);
+    {   // the same XYZZ kernel 40 times back to back (~0.3 s): does the rate hold once the chip has settled at its sustained clock?
+        const float t40 = time_ms([&] { for (int r = 0; r < 40; r++) hipLaunchKernelGGL(k_xyzz, dim3(threads / 128), dim3(128), 0, 0, pts, out); });
+        printf("xyzz mixed addition; 40 launches back to back,%.3f per launch,%.2f,%.3f\n", t40 / 40, adds * 40 / t40 / 1e6, (t40 / 40) / t_x);
+    }
     const float t_i = time_ms([&] { hipLaunchKernelGGL(k_inverse, dim3(threads / 128), dim3(128), 0, 0, pts, out); });
     printf("one Fermat inversion per lane,%.3f,%.3f G inversions/s,= %.1f XYZZ additions\n", t_i / 2, (double)threads * 2 / t_i / 1e6, (t_i / 2 / threads) / (t_x / adds));
     return 0;
