@@ -38,10 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-BYTES_PER_POINT = {0: 96, 1: 128, 2: 128}  # 32 B scalar + affine base
+BYTES_PER_POINT = {0: 96, 1: 128, 2: 128, 3: 160}  # 32 B scalar + affine base; 3 = BN254 G2
 BYTES_PER_NTT_ELEM = 64
-POINT_BYTES = {0: 64, 1: 96, 2: 96}
-RESULT_BYTES = {0: 96, 1: 144, 2: 144}
+POINT_BYTES = {0: 64, 1: 96, 2: 96, 3: 128}
+RESULT_BYTES = {0: 96, 1: 144, 2: 144, 3: 192}
 # v_mad_u64_u32 lane-operations per second, whole chip, 8 waves per SIMD: profiles/r01_ubench_int_rates.txt ("mad_u64_u32 ... 28450.16 Gop/s")
 MAD_PEAK_PER_S = 28.45e12
 # multiply-adds of one XYZZ mixed addition on 9 x 29-bit limbs: 8 products of 162, 2 squarings of 126, one shared reduction
@@ -157,7 +157,7 @@ class MsmProblem:
         self.result = torch.zeros(RESULT_BYTES[curve], dtype=torch.uint8, device=ctx.dev)
         ffi.check(lib.panda_gen_bases(curve, seed, first, n, self.bases.data_ptr(), ctx.pstream), "gen_bases")
         ffi.check(lib.panda_gen_scalars(curve, seed ^ 0xFFFF, first, n, self.scalars.data_ptr(), ctx.pstream), "gen_scalars")
-        self.fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[curve]
+        self.fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381, lib.panda_msm_execute_bn254_g2)[curve]
         self.cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ctx.pstream, self.bases.data_ptr(), self.scalars.data_ptr(), self.result.data_ptr(), log_n, coord)
         self.coord = coord
         self.tables, self.wbits, self.held, self.t_reg = 0, 0, 0, 0.0
@@ -320,6 +320,7 @@ def main():
         leg("config2_msm_2_20", lambda: small_config(ctx, 0, 20, ctx.ffi.JACOBIAN, 20, "BN254 MSM 2^20, Jacobian output, cached bases (BASELINE config 2)"))
         leg("config5_bls12_377_2_24_projective",
             lambda: small_config(ctx, 1, 24, ctx.ffi.PROJECTIVE, 5, "BLS12-377 MSM 2^24 + Projective-output conversion (BASELINE config 5)"))
+        leg("bn254_g2_msm_2_20", lambda: small_config(ctx, 3, 20, ctx.ffi.JACOBIAN, 5, "BN254 G2 MSM 2^20 (SURVEY 8f-4; coordinates in Fq2), Jacobian output, cached bases"))
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         leg("cpu_baseline", lambda: cpu_baseline(args.cpu_sample_log_n))
     if rank == 0:

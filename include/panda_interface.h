@@ -11,8 +11,9 @@
  *   Rust-side repr(C) structs        src/gpu_ffi/common.rs:40-44,89-93,134-138,160-208
  *
  * Part 2 are the four symbols the Rust side declares but the reference never defines
- * (binding.rs:14,16,54-56).  Part 3 is additive (no reference counterpart): BLS12-377,
- * inverse NTT, multi-GPU and synthetic-input / diagnostics entry points.
+ * (binding.rs:14,16,54-56).  Part 3 is additive (no reference counterpart): BLS12-377 / BLS12-381 / BN254 G2,
+ * cached-base registration and tables, the in-call upload pipeline, inverse / coset / bit-reversed NTTs, multi-GPU halves and
+ * synthetic-input / diagnostics entry points.
  *
  * Conventions (unchanged from the reference):
  *   - return value: the HIP runtime's error code cast to unsigned; 0 = success
@@ -152,9 +153,17 @@ panda_error panda_msm_setup_bls12_381(void);
 panda_error panda_msm_execute_bls12_381(const panda_msm_configuration exec_cfg);
 panda_error panda_msm_execute_bls12_381_host(const panda_msm_configuration exec_cfg);
 
+/* BN254 G2 (no counterpart in the reference): the twist y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2+1), scalars as for G1.
+ * An Fq2 element is c0 || c1 (2 x 32 B, Montgomery form); affine base x || y = 128 B (identity <=> x == 0), result X || Y || Z = 192 B.
+ * Curve id 3 wherever a curve id is taken (register / precompute / execute_from_host / gen_bases / debug_curve_op). */
+panda_error panda_msm_setup_bn254_g2(void);
+panda_error panda_msm_execute_bn254_g2(const panda_msm_configuration exec_cfg);
+panda_error panda_msm_execute_bn254_g2_host(const panda_msm_configuration exec_cfg);
+panda_error panda_msm_combine_bn254_g2(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result);
+
 /* Cached bases (README.md "Supports cached bases and scalars"; init_msm, wrapper.rs:122-152): registering a device buffer
  * of 2^log_n affine bases lets the library keep its radix-converted copy between calls instead of re-deriving it in every
- * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377, 2 BLS12-381. */
+ * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377, 2 BLS12-381, 3 BN254 G2. */
 panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream);
 panda_error panda_msm_unregister_bases(const void *d_bases);
 /* Cached bases with precomputed window tables (the lookup-table idea the reference left as a stub, msm_host.cuh:248-265):
@@ -231,7 +240,7 @@ panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 
-/* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377 */
+/* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377, 2 = BLS12-381, 3 = BN254 G2 */
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
 panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);
 

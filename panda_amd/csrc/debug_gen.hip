@@ -252,6 +252,23 @@ void generator_wire(u32 *out, unsigned curve)
     fe_to_wire(out + L, x);
 }
 
+// BN254 G2 generator (the standard one of EIP-197 / arkworks; on the twist y^2 = x^3 + 3/(9+u) and of order r: tests/pyref.py), x = x0 + x1 u
+template <>
+void generator_wire<Ext2<Bn254Fq>>(u32 *out, unsigned)
+{
+    static const u32 c[4][8] = {{0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu},
+                                {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u},
+                                {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u},
+                                {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u}};
+    for (int j = 0; j < 4; j++) {
+        Fe<Bn254Fq> t, k, x;
+        fe_const(k, Bn254Fq::K_TOINT);
+        fe_unpack(t, c[j]);
+        fe_mul(x, t, k);
+        fe_to_wire(out + 8 * j, x);
+    }
+}
+
 template <class F>
 hipError_t gen_bases(unsigned curve, u64 seed, u64 first, u64 n, void *d_out, hipStream_t stream)
 {
@@ -297,10 +314,11 @@ panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, cons
 
 panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream)
 {
-    if (op > 2 || curve > 2) return panda_error_invalid_value;
+    if (op > 2 || curve > 3) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 127) / 128)), block(128);
-    if (curve == 0) hipLaunchKernelGGL(k_curve_op<Bn254Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    if (curve == 3) hipLaunchKernelGGL(k_curve_op<Ext2<Bn254Fq>>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    else if (curve == 0) hipLaunchKernelGGL(k_curve_op<Bn254Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     else if (curve == 1) hipLaunchKernelGGL(k_curve_op<Bls377Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     else hipLaunchKernelGGL(k_curve_op<Bls381Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     hipError_t e = hipGetLastError();
@@ -310,10 +328,10 @@ panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const v
 
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream)
 {
-    if (curve > 2) return panda_error_invalid_value;
+    if (curve > 3) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (curve == 0) hipLaunchKernelGGL(k_gen_scalars<Bn254Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
+    if (curve == 0 || curve == 3) hipLaunchKernelGGL(k_gen_scalars<Bn254Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
     else if (curve == 1) hipLaunchKernelGGL(k_gen_scalars<Bls377Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
     else hipLaunchKernelGGL(k_gen_scalars<Bls381Fr>, grid, block, 0, s, seed, first, n, (u32 *)d_out);
     hipError_t e = hipGetLastError();
@@ -323,12 +341,13 @@ panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uin
 
 panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream)
 {
-    if (curve > 2) return panda_error_invalid_value;
+    if (curve > 3) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     switch (curve) {
     case 0: return static_cast<panda_error>(gen_bases<Bn254Fq>(curve, seed, first, n, d_out, s));
     case 1: return static_cast<panda_error>(gen_bases<Bls377Fq>(curve, seed, first, n, d_out, s));
-    default: return static_cast<panda_error>(gen_bases<Bls381Fq>(curve, seed, first, n, d_out, s));
+    case 2: return static_cast<panda_error>(gen_bases<Bls381Fq>(curve, seed, first, n, d_out, s));
+    default: return static_cast<panda_error>(gen_bases<Ext2<Bn254Fq>>(curve, seed, first, n, d_out, s));
     }
 }
 

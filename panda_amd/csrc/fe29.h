@@ -80,6 +80,27 @@ struct Fe {
     u32 l[F::N];
 };
 
+// quadratic extension B[u] / (u^2 + 1) as a "field descriptor" (fe29_ext2.h): an element is c0's limbs followed by c1's.
+// Functions that are called with explicit template arguments (fe_sub, fe_neg) dispatch on IsExt2 themselves; the rest is overloaded.
+template <class B>
+struct Ext2;
+template <class F>
+struct IsExt2 {
+    static constexpr bool value = false;
+};
+template <class B>
+struct IsExt2<Ext2<B>> {
+    static constexpr bool value = true;
+};
+template <class B>
+PANDA_HD Fe<B> &ext_c0(Fe<Ext2<B>> &a) { return *reinterpret_cast<Fe<B> *>(&a.l[0]); }
+template <class B>
+PANDA_HD Fe<B> &ext_c1(Fe<Ext2<B>> &a) { return *reinterpret_cast<Fe<B> *>(&a.l[B::N]); }
+template <class B>
+PANDA_HD const Fe<B> &ext_c0(const Fe<Ext2<B>> &a) { return *reinterpret_cast<const Fe<B> *>(&a.l[0]); }
+template <class B>
+PANDA_HD const Fe<B> &ext_c1(const Fe<Ext2<B>> &a) { return *reinterpret_cast<const Fe<B> *>(&a.l[B::N]); }
+
 template <class F>
 PANDA_HD void fe_zero(Fe<F> &r)
 {
@@ -406,6 +427,11 @@ struct SubMargin {
 template <class F, int KB>
 PANDA_HD void fe_sub(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
 {
+    if constexpr (IsExt2<F>::value) {
+        fe_sub<typename F::Base, KB>(ext_c0(r), ext_c0(a), ext_c0(b));
+        fe_sub<typename F::Base, KB>(ext_c1(r), ext_c1(a), ext_c1(b));
+        return;
+    } else {
     constexpr int K = KB + SubMargin<F>::value;
     static_assert(K <= 200, "subtraction constant table too small");
     Fe<F> t;
@@ -417,6 +443,7 @@ PANDA_HD void fe_sub(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
         t.l[i] = a.l[i] + F::KP[K][i] - b.l[i];
     }
     fe_norm(r, t);
+    }
 }
 
 // KP[K] with the per-limb bias lowered from 2^31 to 2^30 (same value): for differences that feed a multiplication
@@ -478,6 +505,11 @@ struct SubGrowth {
 template <class F, int KB>
 PANDA_HD void fe_neg(Fe<F> &r, const Fe<F> &a)
 {
+    if constexpr (IsExt2<F>::value) {
+        fe_neg<typename F::Base, KB>(ext_c0(r), ext_c0(a));
+        fe_neg<typename F::Base, KB>(ext_c1(r), ext_c1(a));
+        return;
+    } else {
     constexpr int K = KB + SubMargin<F>::value;
     Fe<F> t;
 #pragma unroll
@@ -488,6 +520,7 @@ PANDA_HD void fe_neg(Fe<F> &r, const Fe<F> &a)
         t.l[i] = F::KP[K][i] - a.l[i];
     }
     fe_norm(r, t);
+    }
 }
 
 // 32-bit wire limbs -> 29-bit limbs (same integer); tight
@@ -704,3 +737,5 @@ PANDA_HD void fe_inv(Fe<F> &r, const Fe<F> &a)
 }
 
 } // namespace panda29
+
+#include "fe29_ext2.h"

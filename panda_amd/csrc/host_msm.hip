@@ -129,6 +129,13 @@ panda_error panda_msm_execute_bls12_377_host(const panda_msm_configuration cfg) 
 
 panda_error panda_msm_execute_bls12_381_host(const panda_msm_configuration cfg) { return static_cast<panda_error>(host_msm<Bls381Fq, Bls381Fr>(cfg)); }
 
+panda_error panda_msm_execute_bn254_g2_host(const panda_msm_configuration cfg) { return static_cast<panda_error>(host_msm<Ext2<Bn254Fq>, Bn254Fr>(cfg)); }
+
+panda_error panda_msm_combine_bn254_g2(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result)
+{
+    return static_cast<panda_error>(combine<Ext2<Bn254Fq>>(partials, count, out_type, result));
+}
+
 panda_error panda_msm_combine_bn254(const void *partials, unsigned count, panda_msm_result_coordinate_type out_type, void *result)
 {
     return static_cast<panda_error>(combine<Bn254Fq>(partials, count, out_type, result));

@@ -172,7 +172,8 @@ hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, co
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
     case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
-    default: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms, stale, pipe);
+    case 2: return panda::msm_execute_bls381(cfg, r, tuning, g_phase_ms, stale, pipe);
+    default: return panda::msm_execute_bn254_g2(cfg, r, tuning, g_phase_ms, stale, pipe);
     }
 }
 
@@ -195,7 +196,8 @@ hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg, const
 
 hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
 {
-    if (curve > 2 || !d_bases || log_n > 26) return hipErrorInvalidValue;
+    if (curve > 3 || !d_bases || log_n > 26) return hipErrorInvalidValue;
+    const unsigned fr = panda::msm_scalar_field_of(curve);
     if (const RegisteredPtr have = lookup_registered(d_bases, log_n, curve)) {
         if (!tabled && !have->tabled) return hipSuccess;
         if (tabled && (have->tabled || log_n < 4)) return hipSuccess; // tables exist (or were not worth building)
@@ -209,12 +211,15 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
     PANDA_TRY(hipGetDevice(&r->device));
     if (tabled) {
         if (window_bits && (window_bits < 4 || window_bits > 24)) return hipErrorInvalidValue;
-        const unsigned c = window_bits ? window_bits : pick_tabled_window_bits(curve, log_n);
-        if (c) r->plan = panda::make_safe_window_plan(curve, c);
+        const unsigned c = window_bits ? window_bits : pick_tabled_window_bits(fr, log_n);
+        if (c) r->plan = panda::make_safe_window_plan(fr, c);
         // sizes the three-level sort has no geometry for (a handful of points) keep the converted copy only
         if (!c || !panda::msm_sort_tabled_supported(log_n, r->plan)) r->tabled = false;
     }
-    PANDA_TRY(curve == 0 ? panda::msm_build_registration_bn254(*r, s) : (curve == 1 ? panda::msm_build_registration_bls377(*r, s) : panda::msm_build_registration_bls381(*r, s)));
+    PANDA_TRY(curve == 0   ? panda::msm_build_registration_bn254(*r, s)
+              : curve == 1 ? panda::msm_build_registration_bls377(*r, s)
+              : curve == 2 ? panda::msm_build_registration_bls381(*r, s)
+                           : panda::msm_build_registration_bn254_g2(*r, s));
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     g_registry.push_back(std::move(r));
     g_registry_count.store(g_registry.size(), std::memory_order_release);
@@ -287,9 +292,12 @@ panda_error panda_msm_execute_bls12_377(const panda_msm_configuration cfg) { ret
 
 panda_error panda_msm_execute_bls12_381(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(2, cfg)); }
 
+panda_error panda_msm_setup_bn254_g2(void) { return panda_success; }
+panda_error panda_msm_execute_bn254_g2(const panda_msm_configuration cfg) { return static_cast<panda_error>(msm_execute(3, cfg)); }
+
 panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configuration cfg, const void *h_scalars, unsigned ranges, panda_stream h2d_stream)
 {
-    if (curve > 2) return panda_error_invalid_value;
+    if (curve > 3) return panda_error_invalid_value;
     const panda::MsmPipeline pipe{h_scalars, ranges, static_cast<hipStream_t>(h2d_stream.handle)};
     return static_cast<panda_error>(msm_execute(curve, cfg, &pipe));
 }

@@ -77,6 +77,12 @@ hipError_t msm_build_registration_bls377(MsmRegistration &r, hipStream_t s);
 hipError_t msm_execute_bls381(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale,
                               const MsmPipeline *pipe);
 hipError_t msm_build_registration_bls381(MsmRegistration &r, hipStream_t s);
+hipError_t msm_execute_bn254_g2(const panda_msm_configuration &cfg, const MsmRegistration *reg, MsmTuning tuning, float *phase_ms, bool *stale,
+                                const MsmPipeline *pipe);
+hipError_t msm_build_registration_bn254_g2(MsmRegistration &r, hipStream_t s);
+
+// scalar field of a curve id (what the digit extraction and the window plans are keyed on): BN254 G2 shares BN254's
+static constexpr inline unsigned msm_scalar_field_of(unsigned curve) { return curve == 3 ? 0u : curve; }
 
 } // namespace panda
 
@@ -102,6 +108,12 @@ struct CurveBls381 {
     typedef Bls381Fq Fq;
     typedef Bls381Fr Fr;
     static constexpr unsigned ID = 2;
+};
+// BN254 G2: the twist over Fq2 = Fq[u] / (u^2 + 1); same scalar field, coordinates of 2 x 8 wire words (affine base 128 B, result 192 B)
+struct CurveBn254G2 {
+    typedef Ext2<Bn254Fq> Fq;
+    typedef Bn254Fr Fr;
+    static constexpr unsigned ID = 3;
 };
 
 // ------------------------------------------------------------------------------- HBM layouts
@@ -192,6 +204,36 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32 *__restrict__ w
         for (int k = 0; k < 2 * L; k++) o[k] = 0;
     }
     store_words<2 * L>(out + i * 2 * L, o);
+}
+
+// Group operations of the kernels outside the hot loop.  Over Fq2 (G2) one full addition is ~50 base multiplications; inlined a dozen
+// times per kernel it made this translation unit take six minutes to compile, so there the merge / reduction kernels call ONE
+// out-of-line copy (G2 is not the path the benchmark times); the prime-field curves keep the inlined code.
+template <class F>
+__device__ __noinline__ void xyzz_add_outlined(Xyzz<F> &acc, const Xyzz<F> &q)
+{
+    xyzz_add(acc, q);
+}
+template <class F>
+__device__ __noinline__ void xyzz_dbl_outlined(Xyzz<F> &r, const Xyzz<F> &p)
+{
+    xyzz_dbl(r, p);
+}
+template <class F>
+__device__ __forceinline__ void xyzz_add_k(Xyzz<F> &acc, const Xyzz<F> &q)
+{
+    if constexpr (IsExt2<F>::value)
+        xyzz_add_outlined(acc, q);
+    else
+        xyzz_add(acc, q);
+}
+template <class F>
+__device__ __forceinline__ void xyzz_dbl_k(Xyzz<F> &r, const Xyzz<F> &p)
+{
+    if constexpr (IsExt2<F>::value)
+        xyzz_dbl_outlined(r, p);
+    else
+        xyzz_dbl(r, p);
 }
 
 // Rows of the caller's wire buffer remembered at registration and compared on every execute (msm.hip, "Staleness").
@@ -406,12 +448,12 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
         load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
         for (u32 t = t0 + 1; t <= t1; t++) {
             load_xyzz<F>(q, pw + (u64)t * 2 * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
     }
     if (MERGE) {
         load_xyzz<F>(q, total + ((u64)w * NB + b) * PW);
-        xyzz_add(acc, q);
+        xyzz_add_k(acc, q);
         store_xyzz<F>(total + ((u64)w * NB + b) * PW, acc);
     } else
         store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
@@ -434,14 +476,14 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
         xyzz_set_identity(acc);
         for (u32 c = t0 + t; c <= t1; c += 256) {
             load_xyzz<F>(q, pw + ((u64)c * 2 + (c == t0 ? 1 : 0)) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
         store_xyzz<F>(lds + t * PW, acc);
         __syncthreads();
         for (unsigned s = 128; s > 0; s >>= 1) {
             if (t < s) {
                 load_xyzz<F>(q, lds + (t + s) * PW);
-                xyzz_add(acc, q);
+                xyzz_add_k(acc, q);
                 store_xyzz<F>(lds + t * PW, acc);
             }
             __syncthreads();
@@ -449,7 +491,7 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
         if (t == 0) {
             if (add) {
                 load_xyzz<F>(q, dst + ((u64)w * NB + b) * PW);
-                xyzz_add(acc, q);
+                xyzz_add_k(acc, q);
             }
             store_xyzz<F>(dst + ((u64)w * NB + b) * PW, acc);
         }
@@ -482,9 +524,9 @@ __global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ b
         u32 b = g * group + j;
         if (b < NB) {
             load_xyzz<F>(q, bw + (u64)b * PW);
-            xyzz_add(run, q);
+            xyzz_add_k(run, q);
         }
-        xyzz_add(sum, run);
+        xyzz_add_k(sum, run);
     }
     store_xyzz<F>(gS + ((u64)w * groups + g) * PW, run);
     store_xyzz<F>(gT + ((u64)w * groups + g) * PW, sum);
@@ -504,7 +546,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
         const u32 *src = gT + (u64)w * groups * PW;
         for (unsigned g = blk * 256 + t; g < groups; g += nblk * 256) {
             load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
     } else {
         const unsigned j = slot - 1;
@@ -514,7 +556,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
             const unsigned g = ((i & ~low) << 1) | (1u << j) | (i & low);
             if (g >= groups) break; // g grows with i
             load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
     }
     store_xyzz<F>(lds + t * PW, acc);
@@ -522,7 +564,7 @@ __global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, co
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -541,14 +583,14 @@ __global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u
     xyzz_set_identity(acc);
     for (unsigned b = t; b < nblk; b += 64) {
         load_xyzz<F>(q, in + (((u64)w * slots + slot) * nblk + b) * PW);
-        xyzz_add(acc, q);
+        xyzz_add_k(acc, q);
     }
     store_xyzz<F>(lds + t * PW, acc);
     __syncthreads();
     for (unsigned s = 32; s > 0; s >>= 1) {
         if (t < s && t + s < nblk) { // partials beyond nblk are the identity
             load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -557,7 +599,7 @@ __global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u
         const unsigned doublings = slot ? (slot - 1 + log_group) : 0;
 #pragma unroll 1
         for (unsigned d = 0; d < doublings; d++) {
-            xyzz_dbl(q, acc);
+            xyzz_dbl_k(q, acc);
             acc = q;
         }
         store_xyzz<F>(out + ((u64)w * slots + slot) * PW, acc);
@@ -582,21 +624,21 @@ __global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS,
     if (x < rows) {
         for (unsigned lo = t; lo < cols; lo += 256) {
             load_xyzz<F>(q, gS + ((u64)x * cols + lo) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
         dst = outR + (u64)x * PW;
     } else if (x < rows + cols) {
         const unsigned lo = x - rows;
         for (unsigned hi = t; hi < rows; hi += 256) {
             load_xyzz<F>(q, gS + ((u64)hi * cols + lo) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
         dst = outC + (u64)lo * PW;
     } else {
         const unsigned hi = x - rows - cols;
         for (unsigned lo = t; lo < cols; lo += 256) {
             load_xyzz<F>(q, gT + ((u64)hi * cols + lo) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
         dst = outT + (u64)hi * PW;
     }
@@ -605,7 +647,7 @@ __global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS,
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -629,7 +671,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
     if (slot == 0) {
         for (unsigned i = t; i < rows; i += 256) {
             load_xyzz<F>(q, inT + (u64)i * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
         }
     } else {
         const bool row_slot = slot <= a;
@@ -640,7 +682,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
         for (unsigned i = t; i < count; i += 256)
             if ((i >> j) & 1u) {
                 load_xyzz<F>(q, src + (u64)i * PW);
-                xyzz_add(acc, q);
+                xyzz_add_k(acc, q);
             }
     }
     store_xyzz<F>(lds + t * PW, acc);
@@ -648,7 +690,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
     for (unsigned s = 128; s > 0; s >>= 1) {
         if (t < s) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -656,7 +698,7 @@ __global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, 
     if (t == 0) {
 #pragma unroll 1
         for (unsigned d = 0; d < doublings; d++) {
-            xyzz_dbl(q, acc);
+            xyzz_dbl_k(q, acc);
             acc = q;
         }
         store_xyzz<F>(out + (u64)slot * PW, acc);
@@ -678,7 +720,7 @@ __global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32
     for (unsigned s = 32; s > 0; s >>= 1) {
         if (t < s && t + s < slots) {
             load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add(acc, q);
+            xyzz_add_k(acc, q);
             store_xyzz<F>(lds + t * PW, acc);
         }
         __syncthreads();
@@ -709,7 +751,7 @@ __global__ void __launch_bounds__(128) k_table_step(const u32 *__restrict__ prev
         xyzz_dbl_affine(p, x, y);
 #pragma unroll 1
         for (unsigned s = 1; s < steps; s++) { // the group has odd order: a doubling never reaches the identity
-            xyzz_dbl(d, p);
+            xyzz_dbl_k(d, p);
             p = d;
         }
         xyzz_to_affine_internal(x, y, p);
@@ -750,7 +792,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     typedef typename C::Fq Fq;
     constexpr int PW = 4 * Fq::N;
     constexpr int LQ = Fq::L;
-    constexpr unsigned curve = C::ID;
+    constexpr unsigned curve = panda::msm_scalar_field_of(C::ID); // the sort and the window plans only care about the scalar field
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     const unsigned log_n = cfg.log_scalars_count;
     if (log_n > 26 || !cfg.bases || !cfg.scalars || !cfg.results) return hipErrorInvalidValue;

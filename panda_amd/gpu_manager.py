@@ -21,13 +21,13 @@ from . import gpu_ffi as ffi
 from .gpu_ffi import JACOBIAN, PROJECTIVE, PandaGpuError  # noqa: F401
 
 FIELD_ELEMENT_LEN = 32  # gpu_manager/mod.rs:14
-BN254, BLS12_377, BLS12_381 = 0, 1, 2
-_POINT_BYTES = {BN254: 64, BLS12_377: 96, BLS12_381: 96}
-_RESULT_BYTES = {BN254: 96, BLS12_377: 144, BLS12_381: 144}
+BN254, BLS12_377, BLS12_381, BN254_G2 = 0, 1, 2, 3
+_POINT_BYTES = {BN254: 64, BLS12_377: 96, BLS12_381: 96, BN254_G2: 128}
+_RESULT_BYTES = {BN254: 96, BLS12_377: 144, BLS12_381: 144, BN254_G2: 192}
 
 
 def _msm_entry(lib, curve: int, host: bool = False):
-    names = {BN254: "bn254", BLS12_377: "bls12_377", BLS12_381: "bls12_381"}
+    names = {BN254: "bn254", BLS12_377: "bls12_377", BLS12_381: "bls12_381", BN254_G2: "bn254_g2"}
     return getattr(lib, f"panda_msm_execute_{names[curve]}" + ("_host" if host else ""))
 
 

@@ -49,7 +49,7 @@ def combine_partials(partials: np.ndarray, curve: int = 0, coordinate_type: int 
     p = np.ascontiguousarray(partials).view(np.uint8)
     count = p.shape[0]
     out = np.zeros(p.shape[1], dtype=np.uint8)
-    fn = (lib.panda_msm_combine_bn254, lib.panda_msm_combine_bls12_377, lib.panda_msm_combine_bls12_381)[curve]
+    fn = (lib.panda_msm_combine_bn254, lib.panda_msm_combine_bls12_377, lib.panda_msm_combine_bls12_381, lib.panda_msm_combine_bn254_g2)[curve]
     ffi.check(fn(C.c_void_p(p.ctypes.data), count, coordinate_type, C.c_void_p(out.ctypes.data)), "SchedulingErr")
     return out
 

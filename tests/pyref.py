@@ -150,3 +150,124 @@ def dft(c: Curve, x, omega: int):
     """y[k] = sum_j x[j] omega^(jk) over Fr on canonical ints."""
     n = len(x)
     return [sum(x[j] * pow(omega, j * k, c.r) for j in range(n)) % c.r for k in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------------- BN254 G2
+# The twist y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2 + 1).  The reference holds nothing for G2 (it is not mentioned anywhere in it):
+# this implementation -- affine arithmetic over pairs of Python ints -- is the only oracle the G2 tests have, pinned by the curve
+# equation and the group order of the standard generator (EIP-197 / arkworks).  Wire format: an Fq2 element is c0 || c1, each 8
+# Montgomery-form u32 limbs; affine x || y = 32 words (identity <=> x == 0), Jacobian X || Y || Z = 48 words.
+BN254_G2 = 3
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def f2_mul(a, b, p):
+    return (a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p
+
+
+def f2_add(a, b, p):
+    return (a[0] + b[0]) % p, (a[1] + b[1]) % p
+
+
+def f2_sub(a, b, p):
+    return (a[0] - b[0]) % p, (a[1] - b[1]) % p
+
+
+def f2_inv(a, p):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % p, -1, p)
+    return a[0] * n % p, -a[1] * n % p
+
+
+def g2_b():
+    p = CURVES[BN254].p
+    return f2_mul((3, 0), f2_inv((9, 1), p), p)
+
+
+def g2_is_on_curve(P) -> bool:
+    p = CURVES[BN254].p
+    x, y = P
+    return f2_mul(y, y, p) == f2_add(f2_mul(f2_mul(x, x, p), x, p), g2_b(), p)
+
+
+def g2_add(P, Q):
+    """Affine addition on the twist; None is the identity."""
+    p = CURVES[BN254].p
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if f2_add(P[1], Q[1], p) == (0, 0):
+            return None
+        lam = f2_mul(f2_mul((3, 0), f2_mul(P[0], P[0], p), p), f2_inv(f2_add(P[1], P[1], p), p), p)
+    else:
+        lam = f2_mul(f2_sub(Q[1], P[1], p), f2_inv(f2_sub(Q[0], P[0], p), p), p)
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam, p), P[0], p), Q[0], p)
+    return x3, f2_sub(f2_mul(lam, f2_sub(P[0], x3, p), p), P[1], p)
+
+
+def g2_mul(k: int, P):
+    R = None
+    while k:
+        if k & 1:
+            R = g2_add(R, P)
+        P = g2_add(P, P)
+        k >>= 1
+    return R
+
+
+def _f2_from_wire(raw):
+    c = CURVES[BN254]
+    return limbs_to_int(raw[:8]) * c.Rq_inv % c.p, limbs_to_int(raw[8:16]) * c.Rq_inv % c.p
+
+
+def _f2_to_wire(v):
+    c = CURVES[BN254]
+    return np.concatenate([int_to_limbs(v[0] * c.Rq % c.p, 8), int_to_limbs(v[1] * c.Rq % c.p, 8)])
+
+
+def g2_decode_affine(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint32).reshape(-1)
+    if not raw[:16].any():
+        return None
+    return _f2_from_wire(raw[:16]), _f2_from_wire(raw[16:32])
+
+
+def g2_encode_affine(P) -> np.ndarray:
+    if P is None:
+        return np.zeros(32, np.uint32)
+    return np.concatenate([_f2_to_wire(P[0]), _f2_to_wire(P[1])])
+
+
+def g2_decode_jacobian(raw):
+    p = CURVES[BN254].p
+    raw = np.ascontiguousarray(raw, dtype=np.uint32).reshape(-1)
+    X, Y, Z = (_f2_from_wire(raw[16 * i:16 * (i + 1)]) for i in range(3))
+    if Z == (0, 0):
+        return None
+    zi = f2_inv(Z, p)
+    zi2 = f2_mul(zi, zi, p)
+    return f2_mul(X, zi2, p), f2_mul(Y, f2_mul(zi2, zi, p), p)
+
+
+def g2_decode_homogeneous(raw):
+    p = CURVES[BN254].p
+    raw = np.ascontiguousarray(raw, dtype=np.uint32).reshape(-1)
+    X, Y, Z = (_f2_from_wire(raw[16 * i:16 * (i + 1)]) for i in range(3))
+    if Z == (0, 0):
+        return None
+    zi = f2_inv(Z, p)
+    return f2_mul(X, zi, p), f2_mul(Y, zi, p)
+
+
+def g2_msm(bases: np.ndarray, scalars: np.ndarray):
+    c = CURVES[BN254]
+    acc = None
+    for b, s in zip(bases, scalars):
+        P = g2_decode_affine(b)
+        if P is not None:
+            acc = g2_add(acc, g2_mul(decode_scalar(c, s), P))
+    return acc

@@ -137,3 +137,51 @@ def test_header_is_plain_c_and_links(tmp_path):
                     "-lpanda-cuda", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     assert int(out) == len(names)
+
+
+def test_g2_reference_is_pinned():
+    """The pure-Python G2 arithmetic the G2 tests lean on: the standard generator lies on the twist y^2 = x^3 + 3/(9+u) and has
+    order r; addition is consistent with scalar multiplication."""
+    import pyref
+    c = pyref.CURVES[0]
+    G = pyref.G2_GEN
+    assert pyref.g2_is_on_curve(G)
+    assert pyref.g2_mul(c.r, G) is None
+    assert pyref.g2_add(pyref.g2_mul(5, G), pyref.g2_mul(7, G)) == pyref.g2_mul(12, G)
+    assert pyref.g2_add(pyref.g2_mul(c.r - 1, G), G) is None
+
+
+def test_g2_host_entry_point_vs_python_reference():
+    """panda_msm_execute_bn254_g2_host (product code: the same fe29 / Fq2 arithmetic as the kernels, compiled for the host) against
+    the Python reference: random multiples of the generator incl. an identity base, P and -P, repeated points; edge scalars; both
+    output coordinate systems; and the combine entry point."""
+    import pyref
+    c = pyref.CURVES[0]
+    rng = np.random.default_rng(0x62)
+    n = 64
+    mult = [int(v) for v in rng.integers(1, 1 << 62, n)]
+    pts = [pyref.g2_mul(m, pyref.G2_GEN) for m in mult]
+    pts[7] = None                                          # identity base (x == 0 on the wire)
+    pts[9] = pts[8]                                        # repeated point
+    pts[11] = (pts[10][0], pyref.f2_sub((0, 0), pts[10][1], c.p))  # P, -P
+    bases = np.stack([pyref.g2_encode_affine(P) for P in pts])
+    scalars = po.gen_scalars(po.F_BN254_FR, 0x63, n)
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    for i, v in enumerate([0, 1, c.r - 1, 2, (1 << 253) + 12345]):
+        scalars[20 + i] = mont(v % c.r)
+    scalars[11] = scalars[10]
+    scalars[9] = scalars[8]
+    want = pyref.g2_msm(bases, scalars)
+    out = pgm.panda_msm_bn254_gpu_host(None, scalars, bases, curve=pgm.BN254_G2)
+    assert out.size == 192
+    assert pyref.g2_decode_jacobian(out.view(np.uint32)) == want
+    lib = ffi.load()
+    hom = np.zeros(192, np.uint8)
+    cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), C.c_void_p(bases.ctypes.data), C.c_void_p(scalars.ctypes.data),
+                               C.c_void_p(hom.ctypes.data), 6, pgm.PROJECTIVE)
+    ffi.check(lib.panda_msm_execute_bn254_g2_host(cfg), "host")
+    assert pyref.g2_decode_homogeneous(hom.view(np.uint32)) == want
+    halves = np.stack([pgm.panda_msm_bn254_gpu_host(None, scalars[h * 32:(h + 1) * 32], bases[h * 32:(h + 1) * 32], curve=pgm.BN254_G2).view(np.uint32)
+                       for h in range(2)])
+    total = multi_gpu.combine_partials(halves, curve=pgm.BN254_G2)
+    assert pyref.g2_decode_jacobian(total.view(np.uint32)) == want

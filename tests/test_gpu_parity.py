@@ -947,7 +947,7 @@ def test_msm_ragged_lengths_and_bad_arguments(gm):
         assert lib.panda_msm_execute_bn254(cfg) == 1
         assert lib.panda_msm_execute_bls12_377(cfg) == 1
     assert lib.panda_msm_precompute_bases(0, None, 10, 0, gm.exec_stream.raw) == 1
-    assert lib.panda_msm_precompute_bases(3, d.ptr, 10, 0, gm.exec_stream.raw) == 1  # curve ids are 0, 1, 2
+    assert lib.panda_msm_precompute_bases(4, d.ptr, 10, 0, gm.exec_stream.raw) == 1  # curve ids are 0 ... 3
     assert lib.panda_msm_precompute_bases(0, d.ptr, 3, 30, gm.exec_stream.raw) == 1
     assert lib.panda_msm_register_bases(0, d.ptr, 27, gm.exec_stream.raw) == 1
     flag = C.c_uint(0)
@@ -1112,3 +1112,154 @@ def test_coset_ntt_bn254(gm, log_n):
     pgm.panda_coset_ntt_bn254_gpu(gm, buf, om, g, log_n, inverse=True)
     assert (buf == x).all()
     del cur
+
+
+# ------------------------------------------------------------------ BN254 G2 (curve id 3, coordinates in Fq2)
+
+def _g2_expected(seed_b, scalars, first=0):
+    """(sum s_i m_i) * G2 for bases m_i * G2 generated by panda_gen_bases(3, seed_b): the linearity identity, evaluated with the
+    oracle's scalar-field arithmetic and one Python scalar multiplication on the twist."""
+    k = pyref.limbs_to_int(po.linear_combination(0, seed_b, scalars, first))
+    return pyref.g2_mul(k, pyref.G2_GEN)
+
+
+def _g2_decode(out, coord=pgm.JACOBIAN):
+    w = np.asarray(out).view(np.uint32)
+    return pyref.g2_decode_homogeneous(w) if coord == pgm.PROJECTIVE else pyref.g2_decode_jacobian(w)
+
+
+def _g2_device_bases(seed, n, first=0):
+    db = DeviceBuffer(n * 128)
+    ffi.check(ffi.load().panda_gen_bases(3, seed, first, n, db.ptr, NULL_STREAM), "gen")
+    bases = db.to_host().reshape(n, 32)
+    db.free()
+    return bases
+
+
+def test_g2_device_generator_and_group_law_vs_python():
+    """panda_gen_bases(3, ...) = m_i * G2 (checked against Python scalar multiplications), and the three group-law kernels over Fq2
+    (madd / add / dbl incl. P + P, P + (-P), identity operands) against affine arithmetic over Python integers."""
+    lib = ffi.load()
+    c = pyref.CURVES[0]
+    n = 48
+    bases = _g2_device_bases(0xD2, n, first=5)
+    pts = [pyref.g2_decode_affine(b) for b in bases]
+    for i in (0, 1, 17, n - 1):
+        assert pts[i] == pyref.g2_mul(po.gen_multiplier(0xD2, 5 + i), pyref.G2_GEN)
+        assert pyref.g2_is_on_curve(pts[i])
+    one = pyref._f2_to_wire((1, 0))
+    jac = np.stack([np.concatenate([b, one]) for b in bases])  # (x, y, 1): the same points as Jacobian triples
+    other = _g2_device_bases(0xD3, n)
+    opts = [pyref.g2_decode_affine(b) for b in other]
+    neg = bases.copy()
+    for i in range(n):
+        neg[i, 16:] = pyref._f2_to_wire(pyref.f2_sub((0, 0), pts[i][1], c.p))
+    ident = np.zeros_like(jac)
+    zero_base = other.copy()
+    zero_base[::5, :16] = 0
+
+    def run(op, A, B):
+        dA, dB, dR = DeviceBuffer.from_host(A), DeviceBuffer.from_host(B), DeviceBuffer(n * 192)
+        ffi.check(lib.panda_debug_curve_op(3, op, dR.ptr, dA.ptr, dB.ptr, n, NULL_STREAM), "op")
+        r = dR.to_host().reshape(n, 48)
+        for d in (dA, dB, dR):
+            d.free()
+        return [pyref.g2_decode_jacobian(x) for x in r]
+
+    assert run(0, jac, other) == [pyref.g2_add(p, q) for p, q in zip(pts, opts)]
+    assert run(0, jac, bases) == [pyref.g2_add(p, p) for p in pts]                      # P + P through the mixed addition
+    assert run(0, jac, neg) == [None] * n                                               # P + (-P)
+    assert run(0, ident, other) == opts
+    assert run(0, jac, zero_base) == [p if i % 5 == 0 else pyref.g2_add(p, q) for i, (p, q) in enumerate(zip(pts, opts))]
+    ojac = np.stack([np.concatenate([b, one]) for b in other])
+    assert run(1, jac, ojac) == [pyref.g2_add(p, q) for p, q in zip(pts, opts)]
+    assert run(1, jac, jac) == [pyref.g2_add(p, p) for p in pts]
+    assert run(1, ident, ojac) == opts and run(1, jac, ident) == pts
+    assert run(2, jac, jac) == [pyref.g2_add(p, p) for p in pts]
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 6, 10, 13])
+def test_msm_bn254_g2_sizes(gm, k):
+    """G2 MSM through the C ABI: device path in both coordinate systems against the linearity identity, the library's CPU entry point
+    (pinned to the Python reference in the CPU suite) at the smaller sizes, and the Python MSM itself at the smallest."""
+    n = 1 << k
+    bases = _g2_device_bases(0xE000 + k, n)
+    scalars = po.gen_scalars(po.F_BN254_FR, 0xE100 + k, n)
+    keep = scalars.copy()
+    want = _g2_expected(0xE000 + k, scalars)
+    for coord in (pgm.JACOBIAN, pgm.PROJECTIVE):
+        gm.set_config(coord)
+        try:
+            out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=pgm.BN254_G2)
+        finally:
+            gm.set_config(pgm.JACOBIAN)
+        assert out.size == 192
+        assert _g2_decode(out, coord) == want
+    assert (scalars == keep).all()
+    if k <= 10:
+        assert _g2_decode(pgm.panda_msm_bn254_gpu_host(gm, scalars, bases, curve=pgm.BN254_G2)) == want
+    if k <= 3:
+        assert pyref.g2_msm(bases, scalars) == want
+
+
+@pytest.mark.parametrize("wbits", [0, 12])
+def test_msm_bn254_g2_tables_edges_and_pipeline(gm, wbits):
+    """Precomputed window tables over Fq2 rows, edge scalars, identity bases, P / -P pairs, and the point-range pipeline."""
+    lib = ffi.load()
+    c = pyref.CURVES[0]
+    k = 12
+    n = 1 << k
+    bases = _g2_device_bases(0xE200, n)
+    mult = [po.gen_multiplier(0xE200, i) for i in range(n)]
+    bases[3::7, :16] = 0                                                   # identity bases
+    p300 = pyref.g2_decode_affine(bases[300])
+    bases[301, :16] = bases[300, :16]
+    bases[301, 16:] = pyref._f2_to_wire(pyref.f2_sub((0, 0), p300[1], c.p))  # -P next to P
+    scalars = po.gen_scalars(po.F_BN254_FR, 0xE201, n)
+    scalars[301] = scalars[300]
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    for i, v in enumerate([0, 1, c.r - 1, 0xBEEF, (1 << 253) + 5]):
+        scalars[10 + i] = mont(v % c.r)
+    # expected: sum over the bases that are still m_i * G2 (identity rows and the P / -P pair drop out)
+    total = 0
+    for i in range(n):
+        if i % 7 == 3 or i in (300, 301):
+            continue
+        total = (total + pyref.decode_scalar(c, scalars[i]) * mult[i]) % c.r
+    want = pyref.g2_mul(total, pyref.G2_GEN)
+    assert _g2_decode(pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=pgm.BN254_G2)) == want
+    idx = gm.add_cached_bases(bases)
+    tables, bits, held = gm.precompute_cached_bases(idx, curve=pgm.BN254_G2, window_bits=wbits)
+    assert tables >= 2 and held == tables * n * 128
+    assert _g2_decode(pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=pgm.BN254_G2)) == want
+    # the same registered set through the upload pipeline (2^12 points: the library lowers the ranges to one; then 2^17 below)
+    ds, dr = DeviceBuffer(n * 32), DeviceBuffer(192)
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, C.c_void_p(gm.d_bases[idx]), ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    ffi.check(lib.panda_msm_execute_from_host(3, cfg, C.c_void_p(scalars.ctypes.data), 4, gm.h2d_stream.raw), "msm")
+    assert _g2_decode(dr.to_host()) == want
+    ds.free()
+    dr.free()
+
+
+def test_msm_bn254_g2_2_17_linearity_tables_and_ranges(gm):
+    """2^17 G2 points generated in HBM: plain, with tables, and in two upload ranges; linearity."""
+    lib = ffi.load()
+    k = 17
+    n = 1 << k
+    db, ds, dr = DeviceBuffer(n * 128), DeviceBuffer(n * 32), DeviceBuffer(192)
+    ffi.check(lib.panda_gen_bases(3, 0xE300, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(3, 0xE301, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scalars = ds.to_host().reshape(n, 8)
+    want = _g2_expected(0xE300, scalars)
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    ffi.check(lib.panda_msm_execute_bn254_g2(cfg), "msm")
+    assert _g2_decode(dr.to_host()) == want
+    ffi.check(lib.panda_msm_precompute_bases(3, db.ptr, k, 0, gm.exec_stream.raw), "precompute")
+    ffi.check(lib.panda_msm_execute_bn254_g2(cfg), "msm")
+    assert _g2_decode(dr.to_host()) == want
+    ffi.check(lib.panda_memset(ds.ptr, 0, n * 32), "memset")
+    ffi.check(lib.panda_msm_execute_from_host(3, cfg, C.c_void_p(scalars.ctypes.data), 2, gm.h2d_stream.raw), "msm")
+    assert _g2_decode(dr.to_host()) == want
+    ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
+    for d in (db, ds, dr):
+        d.free()
