@@ -441,6 +441,13 @@ struct TwiddleCache {
         used = off + bytes;
         return (char *)base + off;
     }
+    TwiddleCache() = default;
+    TwiddleCache(const TwiddleCache &) = delete;
+    TwiddleCache &operator=(const TwiddleCache &) = delete;
+    ~TwiddleCache()
+    {
+        if (base) (void)hipFree(base); // a host thread that exits without panda_ntt_tear_down() does not leak its tables
+    }
     hipError_t release()
     {
         hipError_t e = hipSuccess;
