@@ -66,7 +66,44 @@ Arena &thread_arena()
     return arena;
 }
 
-hipError_t release_thread_arena() { return thread_arena().release(); }
+namespace {
+struct HelperStream {
+    hipStream_t s = nullptr;
+    int device = -1;
+    void drop()
+    {
+        if (s) (void)hipStreamDestroy(s);
+        s = nullptr;
+        device = -1;
+    }
+    ~HelperStream() { drop(); }
+};
+thread_local HelperStream g_helper;
+} // namespace
+
+hipError_t thread_helper_stream(hipStream_t *out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (g_helper.s && g_helper.device != dev) g_helper.drop();
+    if (!g_helper.s) {
+        e = hipStreamCreateWithFlags(&g_helper.s, hipStreamNonBlocking); // ordered against the caller's stream by events only
+        if (e != hipSuccess) {
+            g_helper.s = nullptr;
+            return e;
+        }
+        g_helper.device = dev;
+    }
+    *out = g_helper.s;
+    return hipSuccess;
+}
+
+hipError_t release_thread_arena()
+{
+    g_helper.drop();
+    return thread_arena().release();
+}
 
 } // namespace panda
 

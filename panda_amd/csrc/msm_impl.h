@@ -279,14 +279,7 @@ struct PackedBase {
 template <class F>
 __device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
 {
-#if defined(ACC_EXPERIMENT) && (ACC_EXPERIMENT & 1) // timing experiment only (wrong results): every gather stays inside a small region
-#ifndef ACC_EXPERIMENT_MASK
-#define ACC_EXPERIMENT_MASK 0xfffu
-#endif
-    load_words<2 * F::L>(b.w, bases + (u64)(entry & ACC_EXPERIMENT_MASK) * 2 * F::L);
-#else
     load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
-#endif
 }
 
 // RAW: a negated y comes back un-normalised (limbs < 2^31) -- good enough for the one product it feeds in
@@ -301,11 +294,7 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
     inf = (nz == 0);
     fe_unpack(x, b.w);
     fe_unpack(y, b.w + L);
-#if defined(ACC_EXPERIMENT) && (ACC_EXPERIMENT & 2) // timing experiment only: no conditional negation
-    if (false) {
-#else
     if (entry >> 31) {
-#endif
         Fe<F> ny;
         if constexpr (RAW)
             fe_neg_raw<F, 1>(ny, y); // y is canonical (< p)
@@ -866,30 +855,44 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
     panda::Arena &arena = panda::thread_arena();
-    PANDA_TRY(arena.reserve(sz_bases + sz_sort + (nranges > 1 ? 2 : 1) * sz_bacc + sz_parts + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + sz_lcount + sz_llist + 8192));
+    // Ranges alternate between two lanes -- the caller's stream and a helper stream of this host thread -- each with its own sort
+    // scratch, pieces and range buckets, so that range r+1 is sorted (LDS / HBM work) while range r is still being accumulated
+    // (vector issue); the fix-ups, which all add into the one total, are chained by events.
+    const unsigned lanes = nranges > 1 ? 2u : 1u;
+    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
-    u32 *d_bacc_range = nranges > 1 ? (u32 *)arena.take(sz_bacc) : d_bacc; // buckets of the range in flight, added into d_bacc by its fix-up
-    u32 *d_parts = (u32 *)arena.take(sz_parts);
+    u32 *d_bacc_range[2] = {d_bacc, d_bacc}, *d_parts_l[2] = {nullptr, nullptr}, *d_lcount_l[2] = {nullptr, nullptr}, *d_llist_l[2] = {nullptr, nullptr};
+    for (unsigned l = 0; l < lanes; l++) {
+        if (nranges > 1) d_bacc_range[l] = (u32 *)arena.take(sz_bacc); // buckets of the range in flight on this lane, added into d_bacc by its fix-up
+        d_parts_l[l] = (u32 *)arena.take(sz_parts);
+        d_lcount_l[l] = (u32 *)arena.take(sz_lcount);
+        d_llist_l[l] = (u32 *)arena.take(sz_llist);
+        if (!d_bacc_range[l] || !d_parts_l[l] || !d_lcount_l[l] || !d_llist_l[l]) return hipErrorOutOfMemory;
+    }
     u32 *d_gsum = (u32 *)arena.take(sz_gsum);
     u32 *d_gtsum = (u32 *)arena.take(sz_gsum);
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_win = (u32 *)arena.take(sz_win);
     u32 *d_slots = (u32 *)arena.take(sz_slots);
-    u32 *d_lcount = (u32 *)arena.take(sz_lcount);
-    u32 *d_llist = (u32 *)arena.take(sz_llist);
-    if (!d_bases || !d_bacc || !d_bacc_range || !d_parts || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots || !d_lcount || !d_llist) return hipErrorOutOfMemory;
-    const size_t sort_mark = arena.used; // every range's sort carves its scratch from here again
+    if (!d_bases || !d_bacc || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots) return hipErrorOutOfMemory;
+    const size_t sort_mark[2] = {arena.used, arena.used + panda::align256(sz_sort) + 512}; // a lane's sorts carve their scratch from its mark again
+    hipStream_t lane_stream[2] = {stream, stream};
+    if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
 
     struct PhaseEvents { // destroyed on every exit path
         hipEvent_t ev[8] = {};
-        std::vector<hipEvent_t> uploaded;
+        std::vector<hipEvent_t> uploaded, fixed; // range r: its scalars have arrived / its buckets are in the total
+        hipEvent_t started = nullptr;
         ~PhaseEvents()
         {
             for (auto &e : ev)
                 if (e) (void)hipEventDestroy(e);
             for (auto &e : uploaded)
                 if (e) (void)hipEventDestroy(e);
+            for (auto &e : fixed)
+                if (e) (void)hipEventDestroy(e);
+            if (started) (void)hipEventDestroy(started);
         }
     } phase_events;
     hipEvent_t(&ev)[8] = phase_events.ev;
@@ -915,41 +918,55 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         hipLaunchKernelGGL(k_check_samples, dim3(1), dim3(panda::REG_SAMPLES * 16), 0, stream, (const u32 *)cfg.bases, registration->samples, n, 2u * LQ, d_stale);
     else
         hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
+    if (lanes > 1) { // the helper lane starts after everything the caller's stream held before this call
+        phase_events.fixed.assign(nranges, nullptr);
+        for (auto &e : phase_events.fixed) PANDA_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PANDA_TRY(hipEventCreateWithFlags(&phase_events.started, hipEventDisableTiming));
+        PANDA_TRY(hipEventRecord(phase_events.started, stream));
+        PANDA_TRY(hipStreamWaitEvent(lane_stream[1], phase_events.started, 0));
+    }
     for (unsigned r = 0; r < nranges; r++) { // phases 1..4 of a call in ranges are timed on its last (largest) range
         const bool last = r + 1 == nranges;
+        const unsigned lane = lanes > 1 ? (r & 1u) : 0u;
+        hipStream_t ls = lane_stream[lane];
         const unsigned log_c = range_log(r);
         const u64 row0 = range_row0(r);
         const RangeGeom g = range_geom(log_c);
-        if (h_scalars) PANDA_TRY(hipStreamWaitEvent(stream, phase_events.uploaded[r], 0));
-        arena.used = sort_mark;
+        if (h_scalars) PANDA_TRY(hipStreamWaitEvent(ls, phase_events.uploaded[r], 0));
+        arena.used = sort_mark[lane];
         panda::SortResult sorted{};
         const panda::SortEvents sort_events{last ? ev[1] : nullptr, last ? ev[2] : nullptr};
         const panda::SortPlacement place{nranges > 1 ? log_n : 0u, (uint32_t)row0};
         const void *scalars_r = (const char *)cfg.scalars + row0 * 32;
         if (tabled)
-            PANDA_TRY(panda::msm_sort_tabled(stream, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+            PANDA_TRY(panda::msm_sort_tabled(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
         else
-            PANDA_TRY(panda::msm_sort_plain(stream, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+            PANDA_TRY(panda::msm_sort_plain(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
         if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
         if (h_scalars && !last) PANDA_TRY(upload(r + 1)); // behind this range's sort in host order, beside its kernels on the device
-        if (last) PANDA_TRY(mark(3));
+        if (last) PANDA_TRY(hipEventRecord(ev[3], ls));
         // the first range accumulates straight into the total (zeroed: empty buckets must read as the identity); a later range into
-        // its own array, of which only the non-empty buckets are ever read, by the fix-up that adds them to the total
-        u32 *target = r == 0 ? d_bacc : d_bacc_range;
-        if (r == 0) PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, stream));
-        hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, stream, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
+        // its lane's own array, of which only the non-empty buckets are ever read, by the fix-up that adds them to the total
+        u32 *target = r == 0 ? d_bacc : d_bacc_range[lane];
+        u32 *d_parts = d_parts_l[lane], *d_lcount = d_lcount_l[lane], *d_llist = d_llist_l[lane];
+        if (r == 0) PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, ls));
+        hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
                            NB, g.K, g.chunks);
-        if (last) PANDA_TRY(mark(4));
-        PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, stream));
+        if (last) PANDA_TRY(hipEventRecord(ev[4], ls));
+        PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, ls));
         if (r == 0)
-            hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+            hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + 127) / 128, lists), dim3(128), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
                                d_llist, g.long_cap);
-        else
-            hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + 127) / 128, lists), dim3(128), 0, stream, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+        else {
+            if (lanes > 1) PANDA_TRY(hipStreamWaitEvent(ls, phase_events.fixed[r - 1], 0)); // the total is complete up to the previous range
+            hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + 127) / 128, lists), dim3(128), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
                                d_llist, g.long_cap);
-        hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, stream, d_parts, d_bacc, r == 0 ? 0u : 1u, NB, g.chunks, d_lcount, d_llist, g.long_cap);
+        }
+        hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, ls, d_parts, d_bacc, r == 0 ? 0u : 1u, NB, g.chunks, d_lcount, d_llist, g.long_cap);
+        if (lanes > 1) PANDA_TRY(hipEventRecord(phase_events.fixed[r], ls));
         PANDA_TRY(hipGetLastError());
     }
+    if (lanes > 1) PANDA_TRY(hipStreamWaitEvent(stream, phase_events.fixed[nranges - 1], 0));
     PANDA_TRY(mark(5));
     hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
     if (rowcol) {

@@ -49,6 +49,9 @@ struct Arena {
 
 Arena &thread_arena();
 hipError_t release_thread_arena();
+// a second stream of this host thread on the current device (created on first use, destroyed with the arena): the other lane of an
+// MSM that runs in point ranges
+hipError_t thread_helper_stream(hipStream_t *out);
 
 // drops every cached-bases registration whose buffer lies in the allocation `ptr` belongs to (msm.hip); called by
 // panda_free / panda_free_async before the memory goes back to the allocator
