@@ -134,7 +134,9 @@ struct RegisteredBases : panda::MsmRegistration {
 };
 typedef std::shared_ptr<RegisteredBases> RegisteredPtr;
 std::mutex g_registry_mutex;
-std::vector<RegisteredPtr> g_registry;
+// deliberately never destroyed: entries still registered when the process exits would otherwise call hipFree from a static
+// destructor, after the HIP runtime's own exit handler may already have run (the OS reclaims the memory)
+std::vector<RegisteredPtr> &g_registry = *new std::vector<RegisteredPtr>();
 std::atomic<size_t> g_registry_count{0}; // lets panda_free skip the lock when nothing is registered
 
 RegisteredPtr lookup_registered(const void *wire, unsigned log_n, unsigned curve)

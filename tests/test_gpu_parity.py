@@ -1263,3 +1263,25 @@ def test_msm_bn254_g2_2_17_linearity_tables_and_ranges(gm):
     ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
     for d in (db, ds, dr):
         d.free()
+
+
+def test_process_exit_with_live_registration_and_scratch():
+    """A process that ends without unregistering its bases or tearing the library down must exit cleanly: the registry is never
+    destroyed from a static destructor (the HIP runtime's own exit handler may have run by then); per-thread scratch is."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
+        "from panda_amd import gpu_ffi as ffi\n"
+        "from gpu_util import DeviceBuffer, NULL_STREAM\n"
+        "lib = ffi.load(); n = 1 << 12\n"
+        "db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)\n"
+        "ffi.check(lib.panda_gen_bases(0, 1, 0, n, db.ptr, NULL_STREAM), 'gen')\n"
+        "ffi.check(lib.panda_gen_scalars(0, 2, 0, n, ds.ptr, NULL_STREAM), 'gen')\n"
+        "ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, 12, 0, NULL_STREAM), 'pre')\n"
+        "cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), NULL_STREAM, db.ptr, ds.ptr, dr.ptr, 12, 0)\n"
+        "ffi.check(lib.panda_msm_execute_bn254(cfg), 'msm')\n"
+        "print('bye')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bye" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
