@@ -292,7 +292,8 @@ def main():
             out["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "kernel": "k_accumulate", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
                                      "unit": "T mad lane-ops/s", "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions,
                                      "mads_per_addition": MADS_PER_ADDITION_BN254, "kernel_ms": acc_kernel_ms,
-                                     "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s"}
+                                     "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s (a sub-millisecond launch at the nominal "
+                                                    "2.4 GHz; this kernel sustains ~2.0 GHz at ~1240 W, profiles/r02_accumulate_stalls.txt)"}
 
     def leg(name, fn):
         """Secondary figures never take the contract line down with them: a failure is reported in place of the number."""
