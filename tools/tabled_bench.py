@@ -14,6 +14,10 @@ from panda_amd import gpu_ffi as ffi  # noqa: E402
 from panda_amd import gpu_manager as pgm  # noqa: E402
 
 
+if os.environ.get("PANDA_LIB"):  # timing experiments: another build of the library
+    ffi.LIB_PATH = os.environ["PANDA_LIB"]
+
+
 def run(lib, cfg, reps, names, fn=None):
     fn = fn or lib.panda_msm_execute_bn254
     best = None
