@@ -468,8 +468,9 @@ def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
 
 
 def ntt_sharded_figure(ctx: Ctx, reps: int = 5) -> dict:
-    """N > 1: the slab-sharded forward transform, composed on the devices (multi_gpu.ntt_sharded: panda_ntt_slab_step1_bn254 ->
-    all_to_all_single over RCCL -> panda_ntt_slab_step2_bn254).  Strong: 2^24 elements in total; weak: 2^24 per GPU."""
+    """N > 1: the slab-sharded transform, composed on the devices (multi_gpu.ntt_sharded: panda_ntt_slab_step1_bn254 ->
+    all_to_all_single over RCCL -> panda_ntt_slab_step2_bn254; intt_sharded: the mirrored steps).  Strong: 2^24 elements in total;
+    weak: 2^24 per GPU."""
     torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
     g = ctx.world.bit_length() - 1
     res = {"exchange": f"all_to_all_single ({'RCCL, device buffers' if ctx.nccl else ctx.args.dist_backend + ', staged through the host'}), "
@@ -489,10 +490,15 @@ def ntt_sharded_figure(ctx: Ctx, reps: int = 5) -> dict:
         def refill_only(_timed):
             slab.copy_(keep)
 
+        def step_inverse(_timed):
+            slab.copy_(keep)
+            ctx.multi_gpu.intt_sharded(slab, scratch, omega, total_log, stream=ctx.stream)
+
         dt = ctx.timed(step, 2, reps) / reps
+        dt_inv = ctx.timed(step_inverse, 2, reps) / reps
         dt_copy = ctx.timed(refill_only, 1, reps) / reps
         t = max(dt - dt_copy, 1e-9)
-        res[label] = {"value": (1 << total_log) / t, "ms": t * 1e3, "log_n_total": total_log, "elements_per_gpu": m,
+        res[label] = {"value": (1 << total_log) / t, "ms": t * 1e3, "inverse_ms": max(dt_inv - dt_copy, 1e-9) * 1e3, "log_n_total": total_log, "elements_per_gpu": m,
                       "exchange_bytes_per_gpu": m * 32 * (ctx.world - 1) // ctx.world,
                       "scaling": "strong" if label.startswith("strong") else "weak"}
         del slab, scratch, keep

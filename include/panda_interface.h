@@ -239,6 +239,11 @@ panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg);
  * synchronisation at the end */
 panda_error panda_ntt_slab_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
+/* The inverse of the sharded transform, from the forward transform's output layout back to its input layout (n^-1 included), by the
+ * mirrored steps: inverse_step1 (size-G inverse transforms) -> the same all-to-all -> inverse_step2 (twiddle w^(-r k2) / n, then the local
+ * inverse transform).  cfg.omega is the FORWARD root.  Enqueued without waiting, flag valid on return. */
+panda_error panda_ntt_slab_inverse_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_inverse_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 
 /* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377, 2 = BLS12-381, 3 = BN254 G2 */
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);

@@ -693,7 +693,7 @@ hipError_t slab_step1(const panda_ntt_slab_configuration &cfg, bool wait)
 
 // multi-GPU step 2: after the all-to-all the slab holds [j1][k2'] (G x m/G); transforms of size G down j1
 template <class Fr>
-hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait)
+hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait, bool inverse = false)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < 2 * cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
@@ -707,7 +707,7 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait)
     }
     TwiddleCache &tw = g_twiddles[TW_SLAB2];
     u32 key[12];
-    twiddle_key<Fr>(key, cfg.log_n, 0x200u | (cfg.log_ranks << 16), (const u32 *)cfg.omega);
+    twiddle_key<Fr>(key, cfg.log_n, 0x200u | (inverse ? 0x400u : 0u) | (cfg.log_ranks << 16), (const u32 *)cfg.omega);
     PANDA_TRY(tw.settle(stream));
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
@@ -722,7 +722,12 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait)
     if (!hit) {
         Fe<Fr> omega, base;
         fe_from_wire(omega, (const u32 *)cfg.omega);
-        fe_pow_u64(base, omega, m); // w^m has order G
+        if (inverse) {
+            Fe<Fr> oi;
+            fe_inv(oi, omega);
+            omega = oi;
+        }
+        fe_pow_u64(base, omega, m); // w^m (w^-m for the inverse) has order G
         build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
     }
     PassArgs a{};
@@ -740,6 +745,55 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait)
     launch_pass<Fr>(cfg.log_ranks, a, (unsigned)(m / a.tile_elems), stream);
     PANDA_TRY(hipGetLastError());
     if (cfg.flag) *(unsigned *)cfg.flag = 1;
+    return slab_finish(tw, key, stream, wait);
+}
+
+// Inverse of the sharded transform, second half (after the exchange): the slab holds B_r[k2]; multiply by w^(-r k2) / n, then the
+// local size-m inverse transform (root w^-G).  The mirror image of slab_step1: twiddle first, passes second.
+template <class Fr>
+hipError_t slab_inverse_local(const panda_ntt_slab_configuration &cfg, bool wait)
+{
+    if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
+    if (cfg.rank >= (1u << cfg.log_ranks)) return hipErrorInvalidValue;
+    hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
+    PANDA_TRY(order_after_null_stream(stream));
+    const unsigned log_m = cfg.log_n - cfg.log_ranks;
+    const u64 m = (u64)1 << log_m;
+    TwiddleCache &tw = g_twiddles[TW_SLAB1];
+    u32 key[12];
+    twiddle_key<Fr>(key, cfg.log_n, 0x300u | (cfg.log_ranks << 16) | (cfg.rank << 20), (const u32 *)cfg.omega);
+    PANDA_TRY(tw.settle(stream));
+    int dev = -1;
+    PANDA_TRY(hipGetDevice(&dev));
+    const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
+    Fe<Fr> omega_inv, omega_m, scale;
+    fe_zero(omega_inv);
+    fe_zero(omega_m);
+    fe_zero(scale);
+    if (!hit) {
+        fe_from_wire(omega_inv, (const u32 *)cfg.omega);
+        inverse_parameters<Fr>(omega_inv, scale, (u64)1 << cfg.log_n); // w^-1 and n^-1
+        fe_pow_u64(omega_m, omega_inv, (u64)1 << cfg.log_ranks);
+        PANDA_TRY(tw.ensure(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+    } else
+        tw.used = 0;
+    tw.valid = false;
+    u32 *d_ta = (u32 *)tw.take(SZ_TA), *d_tb = (u32 *)tw.take(SZ_TB);
+    if (!d_ta || !d_tb) return hipErrorOutOfMemory;
+    if (!hit) {
+        Fe<Fr> base, base_b;
+        fe_pow_u64(base, omega_inv, cfg.rank);
+        build_table<Fr>(stream, base, &scale, (unsigned)std::min<u64>(m, 1u << 16), d_ta); // n^-1 folded into the low table
+        if (log_m > 16) {
+            fe_pow_u64(base_b, base, (u64)1 << 16);
+            build_table<Fr>(stream, base_b, nullptr, 1u << (log_m - 16), d_tb);
+        }
+    }
+    hipLaunchKernelGGL(k_slab_twiddle<Fr>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, (u32 *)cfg.d_slab, d_ta, d_tb, (unsigned)m);
+    PANDA_TRY(hipGetLastError());
+    unsigned passes = 0;
+    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, omega_m, log_m, nullptr, &passes, !hit));
+    if (cfg.flag) *(unsigned *)cfg.flag = passes & 1u;
     return slab_finish(tw, key, stream, wait);
 }
 
@@ -804,6 +858,14 @@ panda_error panda_ntt_slab_step2_bn254(const panda_ntt_slab_configuration cfg) {
 panda_error panda_ntt_slab_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bn254Fr>(cfg, false)); }
 
 panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg, false)); }
+
+// Inverse of the sharded transform: it takes the forward transform's OUTPUT layout (rank q: y[k1 m + q m/G + k2'] at [k1][k2']) back to
+// its INPUT layout (rank r: x[r + G j2]), n^-1 included, by running the steps backwards: size-G inverse transforms down k1
+// (inverse_step1), the same all-to-all, then the twiddle w^(-r k2) / n and the local size-m inverse transform (inverse_step2).
+// cfg.omega is the FORWARD root.  Enqueued on cfg.stream without waiting; flag as for the forward steps.
+panda_error panda_ntt_slab_inverse_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bn254Fr>(cfg, false, true)); }
+
+panda_error panda_ntt_slab_inverse_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_inverse_local<Bn254Fr>(cfg, false)); }
 
 panda_error panda_ntt_execute_bn254_coset(const panda_ntt_configuration_v1 cfg, const void *shift)
 {

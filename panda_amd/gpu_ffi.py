@@ -73,7 +73,7 @@ ADDITIVE_SYMBOLS = [
     "panda_msm_register_bases", "panda_msm_unregister_bases", "panda_msm_execute_from_host", "panda_msm_precompute_bases", "panda_msm_registered_info", "panda_msm_set_reduce_group", "panda_msm_setup_bls12_377", "panda_msm_execute_bls12_377", "panda_msm_execute_bls12_377_host", "panda_msm_set_window_bits",
     "panda_msm_last_phase_ms", "panda_msm_phase_name", "panda_ntt_execute_bn254_inverse", "panda_ntt_execute_bls12_377_v1", "panda_ntt_execute_bls12_377_inverse", "panda_msm_combine_bn254",
     "panda_msm_combine_bls12_377", "panda_msm_setup_bn254_g2", "panda_msm_execute_bn254_g2", "panda_msm_execute_bn254_g2_host", "panda_msm_combine_bn254_g2", "panda_msm_setup_bls12_381", "panda_msm_execute_bls12_381", "panda_msm_execute_bls12_381_host", "panda_msm_combine_bls12_381",
-    "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
+    "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_ntt_slab_inverse_step1_bn254_enqueue", "panda_ntt_slab_inverse_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
     "panda_debug_field_op", "panda_debug_curve_op", "panda_version",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
         "panda_ntt_execute_bn254_coset": [NttconfigurationV1, vp], "panda_ntt_execute_bn254_coset_inverse": [NttconfigurationV1, vp],
         "panda_ntt_slab_step1_bn254": [NttSlabConfiguration], "panda_ntt_slab_step2_bn254": [NttSlabConfiguration],
         "panda_ntt_slab_step1_bn254_enqueue": [NttSlabConfiguration], "panda_ntt_slab_step2_bn254_enqueue": [NttSlabConfiguration],
+        "panda_ntt_slab_inverse_step1_bn254_enqueue": [NttSlabConfiguration], "panda_ntt_slab_inverse_step2_bn254_enqueue": [NttSlabConfiguration],
         "panda_gen_scalars": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream], "panda_gen_bases": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream],
         "panda_debug_field_op": [u, u, vp, vp, vp, sz, PandaStream], "panda_debug_curve_op": [u, u, vp, vp, vp, sz, PandaStream],
     }

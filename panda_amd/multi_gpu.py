@@ -98,7 +98,9 @@ def _slab_step(step: int, pstream, d_slab: int, d_scratch: int, omega: np.ndarra
     flag = C.c_uint(7)
     cfg = ffi.NttSlabConfiguration(pstream, C.c_void_p(d_slab), C.c_void_p(d_scratch), C.c_void_p(omega.ctypes.data), log_n, log_ranks, rank,
                                    C.pointer(flag))
-    if wait:
+    if step < 0:  # the mirrored steps of the inverse transform (enqueue only)
+        fn = lib.panda_ntt_slab_inverse_step1_bn254_enqueue if step == -1 else lib.panda_ntt_slab_inverse_step2_bn254_enqueue
+    elif wait:
         fn = lib.panda_ntt_slab_step1_bn254 if step == 1 else lib.panda_ntt_slab_step2_bn254
     else:
         fn = lib.panda_ntt_slab_step1_bn254_enqueue if step == 1 else lib.panda_ntt_slab_step2_bn254_enqueue
@@ -148,6 +150,65 @@ def ntt_sharded(slab, scratch, omega, log_n: int, group=None, stream=None):
         flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, rank, wait=False)
         s.synchronize()
     return src if flag else dst
+
+
+def intt_sharded(slab, scratch, omega, log_n: int, group=None, stream=None):
+    """The inverse of ntt_sharded: `slab` holds this rank's part of the forward transform's OUTPUT (rank q: y[k1 m + q m/G + k2'] at
+    [k1][k2']); returns whichever of slab / scratch ends up holding this rank's part of the INPUT layout (rank r: x[r + G j2]), n^-1
+    included.  The steps run backwards: size-G inverse transforms, the same all-to-all, twiddle and the local inverse transform.
+    `omega` is the forward root."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    g = _log2_exact(world)
+    om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+    assert slab.is_cuda and scratch.is_cuda and slab.numel() == scratch.numel() == ((1 << log_n) >> g) * 32
+    s = stream if stream is not None else torch.cuda.current_stream(slab.device)
+    pstream = ffi.PandaStream(s.cuda_stream)
+    with torch.cuda.stream(s):
+        flag = _slab_step(-1, pstream, slab.data_ptr(), scratch.data_ptr(), om, log_n, g, rank, wait=False)
+        src, dst = (scratch, slab) if flag else (slab, scratch)
+        if dist.get_backend(group) == "nccl":
+            dist.all_to_all_single(dst, src, group=group)  # row r of every rank -> rank r: the forward exchange run backwards
+        else:
+            recv = torch.empty(src.numel(), dtype=torch.uint8)
+            dist.all_to_all_single(recv, src.cpu(), group=group)
+            dst.copy_(recv)
+        flag = _slab_step(-2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, rank, wait=False)
+        s.synchronize()
+    return src if flag else dst
+
+
+def intt_sharded_one_process(outs, scratches, omega, log_n: int, stream=None):
+    """intt_sharded with all G ranks played by one process on one GPU (device-to-device copies for the exchange); `outs` are the
+    forward transform's per-rank outputs.  Returns the per-rank input slabs."""
+    import torch
+
+    world = len(outs)
+    g = _log2_exact(world)
+    om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+    s = stream if stream is not None else torch.cuda.current_stream(outs[0].device)
+    pstream = ffi.PandaStream(s.cuda_stream)
+    res = []
+    with torch.cuda.stream(s):
+        pairs = []
+        for q in range(world):
+            flag = _slab_step(-1, pstream, outs[q].data_ptr(), scratches[q].data_ptr(), om, log_n, g, q, wait=False)
+            pairs.append((scratches[q], outs[q]) if flag else (outs[q], scratches[q]))
+        s.synchronize()
+        for r in range(world):
+            dst = pairs[r][1].view(world, -1)
+            for q in range(world):
+                dst[q].copy_(pairs[q][0].view(world, -1)[r])
+        s.synchronize()
+        for r in range(world):
+            src, dst = pairs[r]
+            flag = _slab_step(-2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, r, wait=False)
+            res.append(src if flag else dst)
+        s.synchronize()
+    return res
 
 
 def ntt_sharded_one_process(slabs, scratches, omega, log_n: int, stream=None):

@@ -49,6 +49,8 @@ def main():
         dist.all_gather(gathered, mine)
         y = multi_gpu.natural_from_slab_outputs([t.numpy().view(np.uint32).reshape(m, 8) for t in gathered])
         ok = (y == po.ntt(fid, x, om, log_n)).all()
+        back = multi_gpu.intt_sharded(out.clone(), torch.empty_like(out), om, log_n)  # the inverse returns this rank's input slab
+        ok = ok and (back.cpu().numpy().view(np.uint32).reshape(m, 8) == multi_gpu.slab_of(x, world, rank)).all()
     else:
         # sharded NTT on a box without a GPU: the exchange and the layouts are the product's (multi_gpu.py); the two local
         # steps are stood in by the oracle because their product implementation is a HIP kernel ("ntt_device" above and

@@ -439,6 +439,11 @@ def test_ntt_sharded_composed_on_device(gm, log_ranks, log_n):
     outs = multi_gpu.ntt_sharded_one_process(slabs, scratches, om, log_n)
     y = multi_gpu.natural_from_slab_outputs([o.cpu().numpy().view(np.uint32).reshape(m, 8) for o in outs])
     assert (y == po.ntt(fid, x, om, log_n)).all()
+    # and back: the mirrored steps take the forward output layout to the decimated input layout, n^-1 included
+    spare = [torch.empty_like(t) for t in outs]
+    back = multi_gpu.intt_sharded_one_process([o.clone() for o in outs], spare, om, log_n)
+    for r in range(G):
+        assert (back[r].cpu().numpy().view(np.uint32).reshape(m, 8) == multi_gpu.slab_of(x, G, r)).all(), r
 
 
 def test_msm_config4_partition_8_ranges_of_2_23(gm):
