@@ -34,6 +34,26 @@ def main():
         ok = (buf == po.ntt(fid, x, om, k)).all()
         calls[fid](buf, om, k, True)
         ok = ok and (buf == x).all()
+        if ok and fid == po.F_BN254_FR:  # the other BN254 orderings: bit-reversed output / input, and the sharded composition with its inverse
+            want = po.ntt(fid, x, om, k)
+            perm = np.array([int(format(i, f"0{k}b")[::-1], 2) if k else 0 for i in range(1 << k)])
+            buf = x.copy()
+            pgm.panda_ntt_bn254_gpu_bitrev(gm, buf, om, k)
+            ok = (buf[perm] == want).all()
+            pgm.panda_ntt_bn254_gpu_bitrev(gm, buf, om, k, inverse=True)
+            ok = ok and (buf == x).all()
+            g = int(rng.integers(1, 4))
+            if ok and k >= 2 * g:
+                import torch
+                from panda_amd import multi_gpu
+                G, m = 1 << g, (1 << k) >> g
+                dev = torch.device("cuda", 0)
+                slabs = [torch.from_numpy(multi_gpu.slab_of(x, G, r).view(np.uint8).reshape(-1).copy()).to(dev) for r in range(G)]
+                outs = multi_gpu.ntt_sharded_one_process(slabs, [torch.empty_like(t) for t in slabs], om, k)
+                y = multi_gpu.natural_from_slab_outputs([o.cpu().numpy().view(np.uint32).reshape(m, 8) for o in outs])
+                ok = (y == want).all()
+                back = multi_gpu.intt_sharded_one_process([o.clone() for o in outs], [torch.empty_like(o) for o in outs], om, k)
+                ok = ok and all((back[r].cpu().numpy().view(np.uint32).reshape(m, 8) == multi_gpu.slab_of(x, G, r)).all() for r in range(G))
         if not ok:
             bad += 1
             print("MISMATCH", dict(fid=fid, k=k), flush=True)
