@@ -1290,3 +1290,44 @@ def test_process_exit_with_live_registration_and_scratch():
         "print('bye')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "bye" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("log_n", [25, 26])
+def test_ntt_beyond_three_passes(gm, log_n):
+    """2^25 and 2^26 elements: a fourth pass of degree 1 / 2 whose inter-pass twiddle has a 25 / 26-bit exponent (the two-table path with
+    k split at 16 - deg bits).  Forward values by direct O(n) evaluation of three outputs, the whole inverse(forward(x)) buffer byte for
+    byte, and the bit-reversed orderings against the natural ones at sampled positions."""
+    fid = po.F_BN254_FR
+    n = 1 << log_n
+    lib = ffi.load()
+    om = po.root_of_unity(fid, log_n)
+    rng = np.random.default_rng(log_n)
+    d_a, d_b = DeviceBuffer(n * 32), DeviceBuffer(n * 32)
+    ffi.check(lib.panda_gen_scalars(0, 0x2600 + log_n, 0, n, d_a.ptr, NULL_STREAM), "gen")
+    x = d_a.to_host().reshape(n, 8)
+    flag = C.c_uint(9)
+    cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+    ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
+    assert flag.value == 0  # four passes (fft.cu:193-211)
+    fwd, other = (d_b, d_a) if flag.value else (d_a, d_b)
+    ks = [1, n - 1, int(rng.integers(0, n))]
+    vals = {k: fwd.to_host(nbytes=32, offset=k * 32) for k in ks}
+    for k in ks:
+        assert (vals[k] == po.ntt_eval_at(fid, x, om, log_n, k)).all(), k
+    cfg2 = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, fwd.ptr, other.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+    ffi.check(lib.panda_ntt_execute_bn254_inverse(cfg2), "intt")
+    res, spare = (other, fwd) if flag.value else (fwd, other)
+    assert np.array_equal(res.to_host().reshape(n, 8), x)
+    # bit-reversed output of the same input: y[k] sits at bitrev(k)
+    cfg3 = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, res.ptr, spare.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+    ffi.check(lib.panda_ntt_execute_bn254_bitrev_out(cfg3), "ntt")
+    br, spare = (spare, res) if flag.value else (res, spare)
+    for k in ks:
+        pos = int(format(k, f"0{log_n}b")[::-1], 2)
+        assert (br.to_host(nbytes=32, offset=pos * 32) == vals[k]).all(), k
+    cfg4 = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, br.ptr, spare.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+    ffi.check(lib.panda_ntt_execute_bn254_inverse_bitrev_in(cfg4), "intt")
+    back = spare if flag.value else br
+    assert np.array_equal(back.to_host().reshape(n, 8), x)
+    d_a.free()
+    d_b.free()
