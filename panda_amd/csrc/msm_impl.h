@@ -342,8 +342,14 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     // which meets a boundary in one iteration out of two -- stalled for an HBM round trip each time (k_accumulate ran
     // 14.5 ms with the rows in HBM against 12.2 ms with L2-resident rows: profiles/r02_accumulate_stalls.txt).
     PackedBase<F> next_base;
-    u32 cur_entry = sw[start];
-    u32 ahead_entry = start + 1 < end ? sw[start + 1] : 0u;
+    // The sorted words of a chunk are read four at a time: a lane walks its own 512-byte stretch of the list, so a 4-byte load per
+    // entry fetched the same 64-byte sector sixteen times over -- long after the L2 had let go of it (FETCH_SIZE: 17.8 GB per launch
+    // against 12.9 GB of rows + 0.8 GB of words).
+    const bool quads = ((reinterpret_cast<uintptr_t>(sw + start) & 15) == 0); // chunk starts are multiples of K >= 16 words; tiny lists may not be aligned
+    uint4 quad = make_uint4(0, 0, 0, 0);
+    if (quads) quad = *reinterpret_cast<const uint4 *>(sw + start); // at most 12 bytes past the list's end, inside the arena
+    u32 cur_entry = quads ? quad.x : sw[start];
+    u32 ahead_entry = quads ? quad.y : (start + 1 < end ? sw[start + 1] : 0u);
     fetch_base<F>(next_base, bases, cur_entry);
     for (u32 pos = start; pos < end; pos++) {
         Fe<F> cx, cy;
@@ -369,7 +375,14 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
         if (pos + 1 < end) {
             cur_entry = ahead_entry;
             fetch_base<F>(next_base, bases, cur_entry);
-            if (pos + 2 < end) ahead_entry = sw[pos + 2];
+            if (pos + 2 < end) {
+                if (quads) {
+                    const u32 idx = pos + 2 - start;
+                    if ((idx & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(sw + pos + 2);
+                    ahead_entry = (idx & 2u) ? ((idx & 1u) ? quad.w : quad.z) : ((idx & 1u) ? quad.y : quad.x);
+                } else
+                    ahead_entry = sw[pos + 2];
+            }
         }
         if (boundary) continue;
         if (cinf) continue;
