@@ -868,7 +868,8 @@ def test_msm_batched_pipeline_over_cached_bases(gm, tabled):
 
 
 @pytest.mark.parametrize("cid,k,tabled,chunks,source", [(0, 17, True, 2, "pageable"), (0, 19, True, 8, "pinned"), (0, 19, False, 4, "pinned"), (0, 20, True, 4, "resident"),
-                                                         (1, 18, True, 4, "pageable"), (0, 18, True, 64, "pinned"), (0, 15, True, 4, "pinned"), (0, 18, None, 4, "pinned")])
+                                                         (1, 18, True, 4, "pageable"), (0, 18, True, 64, "pinned"), (0, 15, True, 4, "pinned"), (0, 18, None, 4, "pinned"),
+                                                         (0, 18, True, 3, "pinned_same_stream"), (0, 18, False, 3, "pinned_null_stream")])
 def test_msm_upload_pipeline_inside_one_call(gm, cid, k, tabled, chunks, source):
     """panda_msm_execute_from_host cuts one MSM into point ranges, uploads range r+1 while range r is accumulated against
     its own rows of the registered tables, merges the ranges' buckets on the device.  Same group element as the ordinary call, for
@@ -890,6 +891,11 @@ def test_msm_upload_pipeline_inside_one_call(gm, cid, k, tabled, chunks, source)
     elif tabled is False:
         ffi.check(lib.panda_msm_register_bases(cid, db.ptr, k, gm.exec_stream.raw), "register")
     pinned = C.c_void_p()
+    h2d = gm.h2d_stream.raw
+    if source == "pinned_same_stream":  # copies and kernels on ONE stream: no overlap, same answer
+        h2d, source = gm.exec_stream.raw, "pinned"
+    elif source == "pinned_null_stream":  # the legacy NULL stream as copy stream
+        h2d, source = NULL_STREAM, "pinned"
     if source == "pinned":
         ffi.check(lib.panda_malloc_host(C.byref(pinned), n * 32), "malloc_host")
         C.memmove(pinned, scalars.ctypes.data, n * 32)
@@ -903,7 +909,7 @@ def test_msm_upload_pipeline_inside_one_call(gm, cid, k, tabled, chunks, source)
         ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(scalars.ctypes.data), n * 32), "memcpy")
     for coord in (pgm.JACOBIAN, pgm.PROJECTIVE):
         cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, coord)
-        ffi.check(lib.panda_msm_execute_from_host(cid, cfg, h_ptr, chunks, gm.h2d_stream.raw), "msm")
+        ffi.check(lib.panda_msm_execute_from_host(cid, cfg, h_ptr, chunks, h2d), "msm")
         got = dr.to_host()
         assert ((po.hom_to_affine(cid, got) if coord == pgm.PROJECTIVE else po.to_affine(cid, got)) == want).all()
     assert (ds.to_host().reshape(n, 8) == scalars).all()  # the whole scalar set arrived on the device
