@@ -448,21 +448,30 @@ def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
     cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), ctx.pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
 
     def timed(fn):
-        ts = []
+        """median of `reps` calls: (device time of the passes from the library's own HIP events on the launch stream -- SURVEY 8d's
+        t_exec, first kernel to result ready --, host wall time of the synchronous call)"""
+        dev_ts, wall_ts = [], []
+        ms = C.c_float(0)
         for r in range(reps + 1):
             t = time.perf_counter()
             ffi.check(fn(cfg), "ntt")
+            w = time.perf_counter() - t
+            ffi.check(lib.panda_ntt_last_device_ms(C.byref(ms)), "ntt_ms")
             if r:
-                ts.append(time.perf_counter() - t)
-        ts.sort()
-        return ts[len(ts) // 2]
+                wall_ts.append(w)
+                dev_ts.append(ms.value * 1e-3)
+        dev_ts.sort()
+        wall_ts.sort()
+        return dev_ts[len(dev_ts) // 2], wall_ts[len(wall_ts) // 2]
 
-    fwd = timed(lib.panda_ntt_execute_bn254_v1)
-    inv = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
+    fwd, fwd_wall = timed(lib.panda_ntt_execute_bn254_v1)
+    inv, inv_wall = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
     return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3,
             "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv, "forward_plus_inverse_ms": (fwd + inv) * 1e3,
             "forward_plus_inverse_elements_per_s": n / (fwd + inv),
+            "timing": "ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); wall_ms = host time of the synchronous call",
+            "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 

@@ -197,6 +197,8 @@ const char *panda_msm_phase_name(unsigned phase);
 /* Inverse transform: runs the forward passes with omega^-1 and fuses the n^-1 scaling into the last pass.
  * d_omega is the FORWARD root (host pointer), as for _v1. */
 panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exec_cfg);
+/* device time of the passes of the last panda_ntt_execute_* on this host thread (HIP events on the launch stream), milliseconds */
+panda_error panda_ntt_last_device_ms(float *ms);
 /* Bit-reversed orderings (SURVEY 8f-4 "bit-reversed NTT variants"): the forward transform with y[k] stored at bitrev(k), and the inverse
  * (n^-1 fused) of a buffer in that order back to natural-order coefficients.  Chaining them skips two permutations. */
 panda_error panda_ntt_execute_bn254_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);

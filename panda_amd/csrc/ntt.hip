@@ -146,15 +146,35 @@ struct Rounds {
     static constexpr bool REDUCE_SUM = !LAST && (2 * (2 * BC) + 1) >= LIM;
     static constexpr int NEXT = LAST ? 2 * BC + 1 : (REDUCE_SUM ? 2 : 2 * BC);
     static constexpr int FINAL = Rounds<Fr, DEG, RND + 1, NEXT>::FINAL;
-    __device__ __forceinline__ static void run(const TilePlanes &u, const TwiddlePlanes &pq, unsigned blk_base, unsigned t)
+    // Rounds whose butterflies fall into at most eight twiddle classes (bit <= 8: the last rounds but one of a 256-point sub-transform)
+    // hand the butterflies of a full tile out BY CLASS: a wave then holds one twiddle only, and the waves of class 0 -- twiddle 1: half
+    // of round 6, a quarter of round 5, an eighth of round 4, 0.44 multiplications per element and pass -- replace the product by a
+    // multiply-free reduction of the difference.  The limb-plane padding keeps the strided accesses of this mapping conflict-free
+    // (element stride 2 bit: banks 4 (j mod 8) + j / 8 and the like are distinct over a half-wave).
+    static constexpr bool BY_CLASS = DEG == 8 && !LAST && ((1u << (DEG - 1)) >> RND) <= 8;
+    __device__ __forceinline__ static void run(const TilePlanes &u, const TwiddlePlanes &pq, unsigned blk_base, unsigned t, unsigned tid, bool full_tile)
     {
         constexpr unsigned R = 1u << DEG;
         constexpr unsigned bit = (R >> 1) >> RND;
-        const unsigned di = t & (bit - 1);
-        const unsigned i0 = (t << 1) - di, i1 = i0 + bit;
+        unsigned base = blk_base, tt = t;
+        bool unit_twiddle = false; // wave-uniform
+        if constexpr (BY_CLASS) {
+            if (full_tile) { // 4 sub-transforms x 128 butterflies over 8 waves
+                constexpr unsigned WPC = 8 / bit;       // waves per class
+                constexpr unsigned PER_SUB = 128 / bit; // butterflies of one class in one sub-transform
+                const unsigned w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+                const unsigned cls = w / WPC;
+                const unsigned c = (w % WPC) * 64 + lane;
+                base = (c / PER_SUB) * R;
+                tt = (c % PER_SUB) * bit + cls;
+                unit_twiddle = cls == 0;
+            }
+        }
+        const unsigned di = tt & (bit - 1);
+        const unsigned i0 = (tt << 1) - di, i1 = i0 + bit;
         Fe<Fr> a, b, s, d;
-        u.load(a, blk_base + i0);
-        u.load(b, blk_base + i1);
+        u.load(a, base + i0);
+        u.load(b, base + i1);
         if (REDUCE_SUM) {
             fe_add_nr(s, a, b); // limbs < 2^31: fe_reduce_small carries first
             fe_reduce_small_2p(s); // < 2p, like the products next to it
@@ -166,24 +186,29 @@ struct Rounds {
             constexpr int K = BC + SubMargin<Fr>::value;
 #pragma unroll
             for (int i = 0; i < NL; i++) d.l[i] = a.l[i] + Fr::KP[K][i] - b.l[i];
+        } else if (BY_CLASS && unit_twiddle) { // the whole wave multiplies by 1: a - b + K p, brought below 2p without a product
+            constexpr int K = BC + SubMargin<Fr>::value;
+#pragma unroll
+            for (int i = 0; i < NL; i++) d.l[i] = a.l[i] + Fr::KP[K][i] - b.l[i];
+            fe_reduce_small_2p(d);
         } else {
-            // every lane multiplies (w^0 = 1 for di == 0: no lane of a wave could skip the product anyway), so the
+            // every lane multiplies (outside the by-class rounds w^0 = 1 sits next to other twiddles in a wave), so the
             // difference can go into the product un-normalised
             Fe<Fr> w, raw;
             fe_sub_raw<Fr, BC>(raw, a, b);
             pq.load(w, di << RND);
             fe_mul(d, raw, w);
         }
-        u.store(s, blk_base + i0);
-        u.store(d, blk_base + i1);
+        u.store(s, base + i0);
+        u.store(d, base + i1);
         __syncthreads();
-        Rounds<Fr, DEG, RND + 1, NEXT>::run(u, pq, blk_base, t);
+        Rounds<Fr, DEG, RND + 1, NEXT>::run(u, pq, blk_base, t, tid, full_tile);
     }
 };
 template <class Fr, int DEG, int BC>
 struct Rounds<Fr, DEG, DEG, BC> {
     static constexpr int FINAL = BC;
-    __device__ __forceinline__ static void run(const TilePlanes &, const TwiddlePlanes &, unsigned, unsigned) {}
+    __device__ __forceinline__ static void run(const TilePlanes &, const TwiddlePlanes &, unsigned, unsigned, unsigned, bool) {}
 };
 
 struct PassArgs {
@@ -273,7 +298,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
     const bool active = tid < (TE >> 1);
     // every thread passes the DEG barriers of the rounds; threads beyond a short tile only wait
     if (active)
-        Rounds<Fr, DEG, 0, 2>::run(u, pq, sub * R, t);
+        Rounds<Fr, DEG, 0, 2>::run(u, pq, sub * R, t, tid, TE == TILE);
     else
         for (int r = 0; r < DEG; r++) __syncthreads();
 
@@ -382,13 +407,32 @@ void launch_pass(unsigned deg, const PassArgs &a, unsigned tiles, hipStream_t s)
 
 // The caller's earlier work on other (blocking) streams must be visible: the reference runs its passes on the
 // legacy NULL stream (fft.cu:201), which implies exactly this dependency.
+struct OrderEvent { // one per host thread and device, created on first use: a transform is 2 ms, an event create + destroy per call showed
+    hipEvent_t ev = nullptr;
+    int device = -1;
+    ~OrderEvent()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+    }
+};
+thread_local OrderEvent g_order_event;
+
 hipError_t order_after_null_stream(hipStream_t stream)
 {
-    hipEvent_t ev;
-    PANDA_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PANDA_TRY(hipEventRecord(ev, nullptr));
-    PANDA_TRY(hipStreamWaitEvent(stream, ev, 0));
-    PANDA_TRY(hipEventDestroy(ev));
+    if (stream == nullptr) return hipSuccess; // the NULL stream is ordered after itself
+    int dev = -1;
+    PANDA_TRY(hipGetDevice(&dev));
+    OrderEvent &oe = g_order_event;
+    if (oe.ev && oe.device != dev) {
+        (void)hipEventDestroy(oe.ev);
+        oe.ev = nullptr;
+    }
+    if (!oe.ev) {
+        PANDA_TRY(hipEventCreateWithFlags(&oe.ev, hipEventDisableTiming));
+        oe.device = dev;
+    }
+    PANDA_TRY(hipEventRecord(oe.ev, nullptr));
+    PANDA_TRY(hipStreamWaitEvent(stream, oe.ev, 0));
     return hipSuccess;
 }
 
@@ -474,6 +518,42 @@ void twiddle_key(u32 (&key)[12], unsigned log_n, unsigned variant, const u32 *om
     for (int i = 0; i < 8; i++) key[3 + i] = omega_wire[i];
     key[11] = 0;
 }
+
+// Device time of the last whole transform on this host thread: HIP events on the launch stream around the passes (what the MSM's
+// phase timers are for its kernels), read by panda_ntt_last_device_ms.  A synchronous call timed from outside also counts the host's
+// wake-up after the last pass (~0.1-0.2 ms of a 2 ms transform).
+struct PassTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int device = -1;
+    float ms = 0.f;
+    hipError_t begin(hipStream_t s)
+    {
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (e0 && device != dev) drop();
+        if (!e0) {
+            if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+            if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+            device = dev;
+        }
+        return hipEventRecord(e0, s);
+    }
+    hipError_t end(hipStream_t s) { return hipEventRecord(e1, s); }
+    void read()
+    {
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, e0, e1) == hipSuccess) ms = v;
+    }
+    void drop()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        e0 = e1 = nullptr;
+    }
+    ~PassTimer() { drop(); }
+};
+thread_local PassTimer g_pass_timer;
 
 // All passes of one local transform of size 2^log_n with root `omega` (internal form).  `scale`, when given,
 // multiplies every output (folded into the last pass's twiddles).  Leaves the result in src when *passes_out
@@ -574,9 +654,13 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
         tw.used = 0;
     tw.valid = false;
     unsigned passes = 0;
+    PassTimer &pt = g_pass_timer;
+    PANDA_TRY(pt.begin(stream));
     PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit, br_in, br_out));
+    PANDA_TRY(pt.end(stream));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
+    pt.read();
     memcpy(tw.key, key, sizeof(key));
     tw.valid = true; // only after the tables are known to be complete
     tw.has_pending = false;
@@ -901,6 +985,13 @@ panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1
 {
     return static_cast<panda_error>(
         ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
+}
+
+panda_error panda_ntt_last_device_ms(float *ms)
+{
+    if (!ms) return panda_error_invalid_value;
+    *ms = g_pass_timer.ms;
+    return panda_success;
 }
 
 panda_error panda_ntt_tear_down(void)
