@@ -610,6 +610,170 @@ PANDA_HD void fe_reduce_small(Fe<F> &a)
     fe_reduce_once(a);
 }
 
+// ------------------------------------------------------------------ products by constants with a precomputed quotient
+//
+// For a constant w in [0, p) keep wq = floor(w R / p) next to it (R = 2^(29 N)).  For any x below 8 R the estimate
+// q = floor(x wq / R) satisfies  x w / p - x / R - 1 < q <= x w / p,  so  x w - q p  is x w mod p up to (x / R + 2) multiples
+// of p -- and, being below R, it is determined by the LOW halves of x w and q p alone.  Against the Montgomery product
+// (2 N^2 multiply-adds, N v_mul_lo for the quotient digits) this is N(N+1)/2 for x w, as many for q p and the top
+// N(N-1)/2 + 2N - 1 of x wq (two guard columns below R keep the truncation error of q under one unit): 143 instead of 162 + 9
+// for N = 9.  No radix factor appears: x w mod p is in whatever form x was (the NTT multiplies wire-form residues by
+// plain-integer twiddles and gets wire-form residues back).
+//
+//   fe_mul_shoup   needs  limb(x) < 2^31 + 2^24 (tight, loose or the output of fe_sub_raw), value(x) < R for the bound given
+//                  gives  tight, value < 3p  (exactly: < (x / R + 2) p)
+template <class F>
+struct FeTw {
+    u32 w[F::N];  // the constant, canonical
+    u32 q[F::N];  // floor(w R / p)
+};
+
+#if defined(FE29_DEVICE_CHAINS)
+template <class F, bool UNIFORM, int C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_hi_col(uint64_t &acc, const uint32_t *x, const uint32_t *wq, uint32_t *q)
+{
+    constexpr int N = F::N;
+    constexpr int I0 = C < N ? 0 : C - N + 1;
+    constexpr int CNT = (C < N ? C : N - 1) - I0 + 1;
+    if constexpr (UNIFORM)
+        MacChain<CNT>::vs(acc, x + I0, wq + (C - I0));
+    else
+        MacChain<CNT>::vv(acc, x + I0, wq + (C - I0));
+    if constexpr (C >= N) q[C - N] = (uint32_t)acc & ((1u << 29) - 1);
+    acc >>= 29;
+}
+template <class F, bool UNIFORM, int... C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_hi_cols(uint64_t &acc, const uint32_t *x, const uint32_t *wq, uint32_t *q, std::integer_sequence<int, C...>)
+{
+    (fe29_shoup_hi_col<F, UNIFORM, F::N - 2 + C>(acc, x, wq, q), ...);
+}
+template <class F, bool UNIFORM, int C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_lo_col(uint64_t &acc, const uint32_t *x, const uint32_t *w, const uint32_t *q, uint32_t *out)
+{
+    if constexpr (UNIFORM)
+        MacChain<C + 1>::vs(acc, x, w + C);
+    else
+        MacChain<C + 1>::vv(acc, x, w + C);
+    MacChain<C + 1>::vs(acc, q, &F::PNEG[C]);
+    out[C] = (uint32_t)acc & ((1u << 29) - 1);
+    if constexpr (C + 1 < F::N) acc >>= 29;
+}
+template <class F, bool UNIFORM, int... C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_lo_cols(uint64_t &acc, const uint32_t *x, const uint32_t *w, const uint32_t *q, uint32_t *out,
+                                                                         std::integer_sequence<int, C...>)
+{
+    (fe29_shoup_lo_col<F, UNIFORM, C>(acc, x, w, q, out), ...);
+}
+#endif
+
+// r = x * w - q * p.  UNIFORM: the constant is the same in every lane of the wave and sits in scalar registers.
+template <class F, bool UNIFORM = false>
+PANDA_HD void fe_mul_shoup(Fe<F> &r, const Fe<F> &x, const u32 *w, const u32 *wq)
+{
+    constexpr int N = F::N;
+    static_assert(RawOperandOk<F>::value, "no column headroom for a raw operand in this field");
+    u32 q[N], out[N];
+    u64 acc = 0;
+#if defined(FE29_DEVICE_CHAINS)
+    fe29_shoup_hi_cols<F, UNIFORM>(acc, x.l, wq, q, std::make_integer_sequence<int, N + 1>()); // columns N-2 .. 2N-2
+    q[N - 1] = (u32)acc & LIMB_MASK;
+    acc = 0;
+    fe29_shoup_lo_cols<F, UNIFORM>(acc, x.l, w, q, out, std::make_integer_sequence<int, N>());
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+    return;
+#endif
+    {
+        FE29_SHADOW_DECL
+#pragma unroll
+        for (int c = N - 2; c <= 2 * N - 2; c++) {
+#pragma unroll
+            for (int i = (c < N ? 0 : c - N + 1); i <= (c < N ? c : N - 1); i++) {
+#if defined(FE29_CHECK)
+                assert(x.l[i] < (1u << 31) + (1u << 24) && wq[c - i] < (1u << 29) && "fe_mul_shoup operand range");
+#endif
+                FE29_MAC(acc, x.l[i], wq[c - i]);
+                FE29_SHADOW_MAC(x.l[i], wq[c - i])
+            }
+            if (c >= N) q[c - N] = (u32)acc & LIMB_MASK;
+            acc >>= LIMB_BITS;
+            FE29_SHADOW_SHIFT()
+        }
+        q[N - 1] = (u32)acc & LIMB_MASK;
+    }
+    {
+        acc = 0;
+        FE29_SHADOW_DECL
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+#pragma unroll
+            for (int i = 0; i <= c; i++) {
+                FE29_MAC(acc, x.l[i], w[c - i]);
+                FE29_SHADOW_MAC(x.l[i], w[c - i])
+                FE29_MAC_CONST(acc, q[i], F::PNEG[c - i]);
+                FE29_SHADOW_MAC(q[i], F::PNEG[c - i])
+            }
+            out[c] = (u32)acc & LIMB_MASK;
+            acc >>= LIMB_BITS;
+            FE29_SHADOW_SHIFT()
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+}
+
+template <class F, bool UNIFORM = false>
+PANDA_HD void fe_mul_shoup(Fe<F> &r, const Fe<F> &x, const FeTw<F> &t)
+{
+    fe_mul_shoup<F, UNIFORM>(r, x, t.w, t.q);
+}
+
+// (w, floor(w R / p)) from w in internal form (w R mod p, tight, < 2p).  w R = k p + (w R mod p) with k the quotient wanted, so
+// k = (w R mod p) * (-p^-1) mod R: one truncated product.  Table construction only.
+template <class F>
+PANDA_HD void fe_shoup_prepare(FeTw<F> &t, const Fe<F> &w_internal)
+{
+    constexpr int N = F::N;
+    Fe<F> wm = w_internal, one, wp;
+    fe_reduce_once(wm);
+    fe_zero(one);
+    one.l[0] = 1;
+    fe_mul(wp, wm, one); // w R / R
+    fe_reduce_once(wp);
+    u64 acc = 0;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+#pragma unroll
+        for (int i = 0; i <= c; i++) acc += (u64)wm.l[i] * F::NINV[c - i];
+        t.q[c] = (u32)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) t.w[i] = wp.l[i];
+}
+
+// limbs < 2^32, value < 2^9 p  ->  tight, [0, 2p): the multiply-add spelling of fe_reduce_small_2p without the carry pass in front.
+// The quotient is estimated from the top limb as it stands: it never overshoots (a >= top 2^(29(N-1)), p < (top(p)+1) 2^(29(N-1)))
+// and what it leaves is below p + (2^9 + 9) 2^(29(N-1)) < 2p (pending carries from below are worth less than 9 units of the top
+// limb).  a - q p is taken as the low N limbs of a + q (R - p), so carries, subtraction and normalisation are one chain of N
+// multiply-adds.
+template <class F>
+PANDA_HD void fe_reduce_mad_2p(Fe<F> &a)
+{
+    constexpr int N = F::N;
+    static_assert(F::P[N - 1] >= (1u << 16), "fe_reduce_mad: top limb of p too narrow for the quotient estimate");
+    constexpr u64 C = (1ull << 52) / ((u64)F::P[N - 1] + 1);
+    const u32 q = (u32)(((u64)a.l[N - 1] * C) >> 52);
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        acc += a.l[i];
+        FE29_MAC_CONST(acc, q, F::PNEG[i]);
+        a.l[i] = (u32)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+}
+
 // any value within the fe_mul input contract -> canonical [0, p), same residue
 template <class F>
 PANDA_HD void fe_canon(Fe<F> &r, const Fe<F> &a)

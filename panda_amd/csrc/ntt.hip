@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "fe29.h"
+#include "ntt_radix8.h"
 #include "panda_internal.h"
 
 using namespace panda29;
@@ -71,6 +72,38 @@ __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u
     for (int i = 0; i < NL; i++) dst[i] = acc.l[i];
 #pragma unroll
     for (int i = NL; i < TW_STRIDE; i++) dst[i] = 0;
+}
+
+// the same powers as (w, floor(w R / p)) pairs for the precomputed-quotient products of k_ntt_pass8 (ntt_radix8.h)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_pow_table2(PowBase pb, unsigned count, unsigned rows_deg, u32 *__restrict__ out)
+{
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const unsigned t = rows_deg ? (idx >> rows_deg) * (idx & ((1u << rows_deg) - 1)) : idx;
+    Fe<Fr> acc, f;
+    if (pb.has_scale) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) acc.l[i] = pb.scale[i];
+    } else
+        fe_one(acc);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if ((t >> j) & 1) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
+            fe_mul(acc, acc, f);
+        }
+    }
+    FeTw<Fr> tw;
+    fe_shoup_prepare(tw, acc);
+    u32 *dst = out + (size_t)idx * panda_ntt8::TW2_STRIDE;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        dst[i] = tw.w[i];
+        dst[NL + i] = tw.q[i];
+    }
+    dst[2 * NL] = dst[2 * NL + 1] = 0;
 }
 
 template <class Fr>
@@ -226,6 +259,7 @@ struct PassArgs {
     unsigned canonical;   // reduce the outputs to [0, p): the last pass of a transform; earlier passes stop at [0, 2p)
     unsigned br_in;       // first pass only: the caller's input is in bit-reversed order (element j sits at bitrev(j))
     unsigned br_out;      // last pass only: leave the output in bit-reversed order (y[k] goes to bitrev(k))
+    unsigned tw_done;     // the previous pass (k_ntt_pass8) multiplied the inter-pass twiddle onto its outputs: none here
 };
 
 template <class Fr, int DEG>
@@ -266,7 +300,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
         const unsigned blk = blk0 + b;
         Fe<Fr> v;
         load_elem(v, A.x + src_index * 8);
-        if (A.lgp != 0 || A.force_tw) {
+        if ((A.lgp != 0 && !A.tw_done) || A.force_tw) {
             const unsigned k = blk & (p - 1);
             if (k * i != 0 || A.force_tw) {
                 Fe<Fr> tw;
@@ -298,11 +332,11 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
     const bool active = tid < (TE >> 1);
     // every thread passes the DEG barriers of the rounds; threads beyond a short tile only wait
     if (active)
-        Rounds<Fr, DEG, 0, 2>::run(u, pq, sub * R, t, tid, TE == TILE);
+        Rounds<Fr, DEG, 0, 3>::run(u, pq, sub * R, t, tid, TE == TILE); // inputs below 3p: what k_ntt_pass8's twiddle product leaves
     else
         for (int r = 0; r < DEG; r++) __syncthreads();
 
-    constexpr int FB = Rounds<Fr, DEG, 0, 2>::FINAL;
+    constexpr int FB = Rounds<Fr, DEG, 0, 3>::FINAL;
     static_assert(FB < 512, "final bound must fit fe_reduce_small (values below 2^9 p)");
     for (unsigned e = tid; e < TE; e += 512) {
         unsigned b, i, lds_i;
@@ -364,9 +398,10 @@ std::mutex g_omega_mutex;
 u32 g_omega_wire[8];
 bool g_omega_set = false;
 
-const size_t SZ_TA = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
-const size_t SZ_TB = panda::align256((size_t)(1u << 16) * TW_STRIDE * 4);
-const size_t SZ_PQ = panda::align256((size_t)128 * TW_STRIDE * 4);
+// sized for the (w, floor(w R / p)) pairs of k_ntt_pass8; k_ntt_pass's 48-byte entries fit too
+const size_t SZ_TA = panda::align256((size_t)(1u << 16) * panda_ntt8::TW2_STRIDE * 4);
+const size_t SZ_TB = panda::align256((size_t)(1u << 16) * panda_ntt8::TW2_STRIDE * 4);
+const size_t SZ_PQ = panda::align256((size_t)128 * panda_ntt8::TW2_STRIDE * 4);
 
 template <class Fr>
 void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
@@ -388,6 +423,29 @@ void build_table(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, un
     PowBase pb;
     fill_pow_base<Fr>(pb, base, scale);
     hipLaunchKernelGGL(k_pow_table<Fr>, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, rows_deg, d_out);
+}
+
+template <class Fr>
+void build_table2(hipStream_t stream, const Fe<Fr> &base, const Fe<Fr> *scale, unsigned count, u32 *d_out, unsigned rows_deg = 0)
+{
+    PowBase pb;
+    fill_pow_base<Fr>(pb, base, scale);
+    hipLaunchKernelGGL(k_pow_table2<Fr>, dim3((count + 255) / 256), dim3(256), 0, stream, pb, count, rows_deg, d_out);
+}
+
+// LDS planes per exchange batch and resident workgroups per CU of k_ntt_pass8 (5 planes: 40 KB + 10 KB of twiddles, three fit)
+constexpr int P8_PLANES = 5, P8_MINW = 3;
+
+template <class Fr>
+void launch_pass8(bool first, bool last, const panda_ntt8::Pass8Args &a, unsigned tiles, hipStream_t s)
+{
+    using namespace panda_ntt8;
+    if (last)
+        hipLaunchKernelGGL((k_ntt_pass8<Fr, false, true, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
+    else if (first)
+        hipLaunchKernelGGL((k_ntt_pass8<Fr, true, false, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_ntt_pass8<Fr, false, false, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
 }
 
 template <class Fr>
@@ -567,47 +625,91 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
     unsigned log_p = 0, passes = 0;
     const unsigned max_deg = log_n < 8 ? log_n : 8; // MAX_LOG2_RADIX, fft.cu:9,177
     const unsigned total_passes = (log_n + 7) / 8;
+    // Transforms of 2^11 points and more run their radix-256 passes in k_ntt_pass8, which multiplies the twiddle between two passes
+    // onto the OUTPUT of the earlier one; a shorter last pass (k_ntt_pass) then finds it done.  Smaller transforms keep the
+    // twiddle on the input side of k_ntt_pass.
+    const bool regs8 = log_n >= 11;
     while (log_p < log_n) {
         const unsigned deg = std::min(max_deg, log_n - log_p);
         const bool last = (passes + 1 == total_passes);
         u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB), *d_pq = (u32 *)arena.take(SZ_PQ);
         if (!d_ta || !d_tb || !d_pq) return hipErrorOutOfMemory;
-        PassArgs a{};
-        a.x = src;
-        a.y = dst;
-        a.pq = d_pq;
-        a.ta = d_ta;
-        a.tb = d_tb;
-        a.log_n = log_n;
-        a.lgp = log_p;
-        a.tile_elems = (unsigned)std::min<u64>(TILE, n);
-        const unsigned mbits = log_p + deg; // bits of the twiddle exponent k * i
-        a.split = (log_p != 0 && mbits > 16) ? 16 - deg : 0;
-        a.force_tw = (scale && last) ? 1 : 0;
-        a.strided_out = 0;
-        a.canonical = last ? 1 : 0;
-        a.br_in = (br_in && passes == 0) ? 1 : 0;
-        a.br_out = (br_out && last) ? 1 : 0;
         Fe<Fr> base;
-        if (build) {
-            fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
-            build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
-            if (log_p != 0) {
-                fe_pow_u64(base, omega, n >> log_p >> deg);
-                if (a.split == 0)
-                    build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << mbits, d_ta);
-                else {
-                    build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << 16, d_ta, deg); // [k_lo][i], k_lo < 2^split
-                    Fe<Fr> base_b;
-                    fe_pow_u64(base_b, base, (u64)1 << a.split);
-                    build_table<Fr>(stream, base_b, nullptr, 1u << (log_p - a.split + deg), d_tb, deg); // [k_hi][i], k_hi < 2^(log_p - split)
+        if (regs8 && deg == 8) {
+            panda_ntt8::Pass8Args a{};
+            a.x = src;
+            a.y = dst;
+            a.pq = d_pq;
+            a.ta = d_ta;
+            a.tb = d_tb;
+            a.log_n = log_n;
+            a.lgp = log_p;
+            a.br_in = (br_in && passes == 0) ? 1 : 0;
+            a.br_out = (br_out && last) ? 1 : 0;
+            const unsigned deg2 = last ? 0 : std::min(8u, log_n - log_p - 8); // radix of the next pass
+            if (!last) {
+                // twiddle W^(i2 k2), W = w^(n / 2^(log_p + 8 + deg2)), k2 < 2^(log_p + 8), i2 < 2^deg2; tables of at most 2^16 entries
+                if (log_p + 8 + deg2 <= 16) {
+                    a.ca = log_p + 8;
+                    a.cb = 0;
+                } else {
+                    a.ca = std::min(log_p, 16 - deg2);
+                    a.cb = log_p + 8 - a.ca;
                 }
-            } else if (a.force_tw) {
-                fe_one(base);
-                build_table<Fr>(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
+                a.i2_shift = log_n - deg2 - log_p - 8;
             }
+            if (build) {
+                fe_pow_u64(base, omega, n >> 8); // butterfly twiddles (w^(n / 256))^t
+                build_table2<Fr>(stream, base, nullptr, 128, d_pq);
+                if (!last) {
+                    fe_pow_u64(base, omega, n >> (log_p + 8) >> deg2);
+                    build_table2<Fr>(stream, base, (scale && passes == 0) ? scale : nullptr, 1u << (deg2 + a.ca), d_ta, a.ca);
+                    if (a.cb) {
+                        Fe<Fr> base_b;
+                        fe_pow_u64(base_b, base, (u64)1 << a.ca);
+                        build_table2<Fr>(stream, base_b, nullptr, 1u << (deg2 + a.cb), d_tb, a.cb);
+                    }
+                }
+            }
+            launch_pass8<Fr>(passes == 0, last, a, (unsigned)(n / panda_ntt8::ELEMS), stream);
+        } else {
+            PassArgs a{};
+            a.x = src;
+            a.y = dst;
+            a.pq = d_pq;
+            a.ta = d_ta;
+            a.tb = d_tb;
+            a.log_n = log_n;
+            a.lgp = log_p;
+            a.tile_elems = (unsigned)std::min<u64>(TILE, n);
+            const unsigned mbits = log_p + deg; // bits of the twiddle exponent k * i
+            a.tw_done = (regs8 && log_p != 0) ? 1 : 0;
+            a.split = (log_p != 0 && mbits > 16 && !a.tw_done) ? 16 - deg : 0;
+            a.force_tw = (scale && last && !regs8) ? 1 : 0; // with k_ntt_pass8 in front the scale sits in the first pass's output twiddles
+            a.strided_out = 0;
+            a.canonical = last ? 1 : 0;
+            a.br_in = (br_in && passes == 0) ? 1 : 0;
+            a.br_out = (br_out && last) ? 1 : 0;
+            if (build) {
+                fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
+                build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
+                if (log_p != 0 && !a.tw_done) {
+                    fe_pow_u64(base, omega, n >> log_p >> deg);
+                    if (a.split == 0)
+                        build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << mbits, d_ta);
+                    else {
+                        build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << 16, d_ta, deg); // [k_lo][i], k_lo < 2^split
+                        Fe<Fr> base_b;
+                        fe_pow_u64(base_b, base, (u64)1 << a.split);
+                        build_table<Fr>(stream, base_b, nullptr, 1u << (log_p - a.split + deg), d_tb, deg); // [k_hi][i], k_hi < 2^(log_p - split)
+                    }
+                } else if (a.force_tw) {
+                    fe_one(base);
+                    build_table<Fr>(stream, base, scale, 1, d_ta); // single pass: the table is just the scale
+                }
+            }
+            launch_pass<Fr>(deg, a, (unsigned)(n / a.tile_elems), stream);
         }
-        launch_pass<Fr>(deg, a, (unsigned)(n / a.tile_elems), stream);
         PANDA_TRY(hipGetLastError());
         const u32 *tmp = dst;
         dst = const_cast<u32 *>(src);

@@ -1,0 +1,413 @@
+// ntt_radix8.h -- one radix-256 pass of the transform with the data held in registers (included by ntt.hip).
+//
+// The pass keeps the reference protocol's shape (src/cuda/core/unit/ntt/fft.cu:171-216: a radix-2^8 pass from one buffer to the
+// other) but not the one-butterfly-per-thread-per-round layout of k_ntt_pass:
+//
+//   * a workgroup of 256 threads owns a tile of 8 sub-transforms (2048 elements); every thread owns EIGHT elements and runs
+//     three butterfly rounds on them in registers, so the 8 rounds are three register blocks (3 + 3 + 2 rounds) with two
+//     exchanges through LDS in between instead of eight LDS round trips with a barrier each.  The elements come from HBM
+//     straight into registers and leave from registers (the thread-to-element maps of the first and last block are chosen so
+//     that a wave touches runs of 256 B or more);
+//   * every product has a constant factor (a twiddle), so it is a precomputed-quotient product (fe_mul_shoup, fe29.h):
+//     143 multiply-adds instead of 171, no radix factor.  Tables hold (w, floor(w R / p)) pairs;
+//   * in the middle block the twiddle of a butterfly depends only on the wave and the register index, so it lives in scalar
+//     registers, and the waves whose twiddle is 1 skip the product; the last block's only twiddle is the 4th root of unity;
+//   * the twiddle between two passes moved from the input of the later pass to the OUTPUT of the earlier one: the product
+//     takes the un-reduced output of the last round (anything below R) and returns a value below 3p, which fits the 32-byte
+//     wire element -- it doubles as the reduction the old kernel ran separately.  Only the last pass of a transform, which
+//     has no twiddle, reduces (to the canonical range);
+//   * LDS is an exchange medium only.  The limbs of a tile travel in batches of PB limb planes (PB * 8 KB per workgroup) so that
+//     three or four workgroups fit a CU next to the registers they need; XOR-swizzled addresses keep both sides of an
+//     exchange free of bank conflicts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fe29.h"
+
+namespace panda_ntt8 {
+using namespace panda29;
+
+constexpr int NL = 9;
+constexpr int TW2_STRIDE = 20; // words per table entry: w[9], floor(w R / p)[9], two words of padding (80 B, five 16-byte loads)
+constexpr int SUBS = 8;        // sub-transforms per tile
+constexpr int ELEMS = 2048;    // elements per tile
+constexpr int THREADS = 256;
+
+struct Pass8Args {
+    const u32 *x;
+    u32 *y;
+    const u32 *pq; // 128 entries: w_256^t, the butterfly twiddles of a 256-point sub-transform
+    const u32 *ta; // output twiddles, see below
+    const u32 *tb;
+    unsigned log_n;
+    unsigned lgp;      // log2 of the product of the radices of the passes before this one
+    unsigned ca;       // the twiddle of output element (blk, i_out) is W^(i2 k2), k2 = i_out 2^lgp + (blk mod 2^lgp) its index within
+    unsigned cb;       // the next pass's sub-transform group and i2 = (blk >> lgp) >> i2_shift its input index there.  cb == 0: one
+    unsigned i2_shift; // lookup ta[(i2 << ca) | k2].  Else two: ta[(i2 << ca) | (k2 mod 2^ca)] (ca <= lgp: one per thread) and
+                       // tb[(i2 << cb) | (k2 >> ca)]
+    unsigned br_in;    // first pass: the caller's input is in bit-reversed order
+    unsigned br_out;   // last pass: leave the output in bit-reversed order
+};
+
+template <class Fr>
+struct TwV {
+    u32 w[NL];
+    u32 q[NL];
+};
+
+template <class Fr>
+__device__ __forceinline__ void tw_from_quads(TwV<Fr> &t, const uint4 &a, const uint4 &b, const uint4 &c, const uint4 &d, const uint4 &e)
+{
+    t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+    t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+    t.w[8] = c.x;
+    t.q[0] = c.y; t.q[1] = c.z; t.q[2] = c.w;
+    t.q[3] = d.x; t.q[4] = d.y; t.q[5] = d.z; t.q[6] = d.w;
+    t.q[7] = e.x; t.q[8] = e.y;
+}
+
+template <class Fr>
+__device__ __forceinline__ void load_tw2(TwV<Fr> &t, const u32 *tab, unsigned idx)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)idx * TW2_STRIDE);
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    tw_from_quads(t, a, b, c, d, e);
+}
+
+// wave-uniform entry: word loads from a uniform address, which the compiler turns into scalar loads
+template <class Fr>
+__device__ __forceinline__ void load_tw2_uniform(TwV<Fr> &t, const u32 *__restrict__ tab, unsigned idx)
+{
+    const u32 *p = tab + idx * TW2_STRIDE;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        t.w[j] = __builtin_amdgcn_readfirstlane(p[j]);
+        t.q[j] = __builtin_amdgcn_readfirstlane(p[NL + j]);
+    }
+}
+
+// ---- compile-time bounds ------------------------------------------------------------------------------------------------------
+// All elements of a pass carry one bound (in units of p) per round.  A butterfly on inputs below B p stores a + b (< 2B p) and
+// either (a - b + K p) w (< 3p out of the product, which needs a - b + K p < R) or, where the twiddle is 1, a - b + K p itself.
+// When the next round could not take the result, this round reduces its un-multiplied outputs below 2p (fe_reduce_mad_2p).
+template <class Fr>
+constexpr int keff_of(int B)
+{
+    return Fr::KEFF[B + SubMargin<Fr>::value];
+}
+template <class Fr>
+constexpr bool round_ok(int B)
+{
+    return B + SubMargin<Fr>::value <= 200 && B + keff_of<Fr>(B) < (int)Fr::HEADROOM;
+}
+template <class Fr, int B0>
+struct Plan8 {
+    int b[9];
+    bool red[8];
+    constexpr Plan8() : b{}, red{}
+    {
+        int B = B0;
+        for (int r = 0; r < 8; r++) {
+            b[r] = B;
+            const int dplain = B + keff_of<Fr>(B);
+            const int dmax = (r >= 3 && dplain > 3) ? dplain : 3; // rounds 0..2 multiply every difference
+            int next = 2 * B > dmax ? 2 * B : dmax;
+            red[r] = r < 7 ? !round_ok<Fr>(next) : next >= (int)Fr::HEADROOM; // the output product wants its operand below R
+            if (red[r]) next = 3;
+            B = next;
+        }
+        b[8] = B;
+    }
+};
+
+template <class Fr, int B0>
+inline constexpr Plan8<Fr, B0> plan8_v{};
+
+// one radix-2 butterfly on registers: a <- a + b, b <- (a - b + K p) [* w].  RAW: leave both outputs un-normalised (limbs < 2^31;
+// the last round, whose outputs go straight into a product or a reduction)
+template <class Fr, int B, bool MULT, bool RED, bool UNIFORM, bool RAW = false>
+__device__ __forceinline__ void bfly(Fe<Fr> &a, Fe<Fr> &b, const u32 *w, const u32 *wq)
+{
+    static_assert(B + SubMargin<Fr>::value <= 200, "subtraction constant table too small");
+    Fe<Fr> s;
+    if constexpr (MULT) {
+        static_assert(round_ok<Fr>(B), "operand of the twiddle product must stay below R");
+        Fe<Fr> x;
+        fe_sub_raw<Fr, B>(x, a, b);
+        if constexpr (RED) {
+            fe_add_nr(s, a, b);
+            fe_reduce_mad_2p(s);
+        } else
+            fe_add(s, a, b);
+        fe_mul_shoup<Fr, UNIFORM>(b, x, w, wq);
+        a = s;
+    } else if constexpr (RAW) {
+        Fe<Fr> d;
+        fe_sub_raw<Fr, B>(d, a, b);
+        fe_add_nr(s, a, b);
+        a = s;
+        b = d;
+    } else {
+        Fe<Fr> d;
+        fe_sub<Fr, B>(d, a, b);
+        if constexpr (RED) {
+            fe_add_nr(s, a, b);
+            fe_reduce_mad_2p(s);
+            fe_reduce_mad_2p(d);
+        } else
+            fe_add(s, a, b);
+        a = s;
+        b = d;
+    }
+}
+
+__device__ __forceinline__ unsigned brev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); } // bits >= 1
+__device__ __forceinline__ unsigned brev0(unsigned v, unsigned bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
+constexpr unsigned br3(unsigned m) { return ((m & 1) << 2) | (m & 2) | ((m >> 2) & 1); }
+
+template <class Fr>
+__device__ __forceinline__ void load_elem32(Fe<Fr> &v, const u32 *__restrict__ src)
+{
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    const uint4 lo = s4[0], hi = s4[1];
+    const u32 w8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    fe_unpack(v, w8);
+}
+template <class Fr>
+__device__ __forceinline__ void store_elem32(u32 *__restrict__ dst, const Fe<Fr> &v) // tight limbs, value < 2^256
+{
+    u32 w8[8];
+    fe_pack(w8, v);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    d4[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+    d4[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+}
+
+// Exchange through LDS, PB limb planes at a time: every thread stores limb planes [p0, p0 + PB) of its eight elements at wa[m],
+// the workgroup meets, every thread loads the same planes of its eight NEW elements from ra + m * RSTEP.  A plane is ELEMS words.
+template <class Fr, int PB, int RSTEP>
+__device__ __forceinline__ void exchange(Fe<Fr> (&e)[8], u32 *s_x, const unsigned (&wa)[8], unsigned ra)
+{
+    Fe<Fr> n[8];
+#pragma unroll
+    for (int p0 = 0; p0 < NL; p0 += PB) {
+        if (p0 != 0) __syncthreads(); // the previous batch has been read by everyone
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+#pragma unroll
+            for (int pl = p0; pl < p0 + PB && pl < NL; pl++) s_x[(pl - p0) * ELEMS + wa[m]] = e[m].l[pl];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+#pragma unroll
+            for (int pl = p0; pl < p0 + PB && pl < NL; pl++) n[m].l[pl] = s_x[(pl - p0) * ELEMS + ra + m * RSTEP];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) e[m] = n[m];
+}
+
+// FIRST: input bound 2 (the caller's elements; nothing was multiplied onto them), else 3 (outputs of the previous pass's twiddle
+// product).  LAST: no output twiddle, canonical output.
+template <class Fr, bool FIRST, bool LAST, int PB, int MINW>
+__global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
+{
+    constexpr const Plan8<Fr, FIRST ? 2 : 3> &PL = plan8_v<Fr, FIRST ? 2 : 3>;
+    __shared__ u32 s_x[PB * ELEMS];
+    __shared__ __attribute__((aligned(16))) u32 s_tw[128 * TW2_STRIDE];
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned blk0 = blockIdx.x * SUBS;
+    const unsigned S = (1u << A.log_n) >> 8; // stride between the inputs of one sub-transform
+    const unsigned lgp = A.lgp;
+
+    // butterfly twiddles of block A -> LDS (2560 words, ten per thread)
+    {
+        const uint2 *g = reinterpret_cast<const uint2 *>(A.pq) + tid * 5;
+        uint2 *l = reinterpret_cast<uint2 *>(s_tw) + tid * 5;
+#pragma unroll
+        for (int j = 0; j < 5; j++) l[j] = g[j];
+    }
+
+    // ---- block A: thread (s, i0) holds i = i0 + 32 m of sub-transform s; rounds 0..2 (distances 128, 64, 32)
+    Fe<Fr> e[8];
+    unsigned s, i0;
+    {
+        size_t base, step;
+        if (A.br_in) {
+            // element j = blk + i S of the natural order sits at bitrev(j) = (bitrev(blk) << 8) + bitrev8(i): a sub-transform is one
+            // contiguous run, a thread's eight elements (i = i0 + 32 m -> bitrev5(i0) * 8 + bitrev3(m)) are 256 contiguous bytes
+            const unsigned bi = lane & 31;
+            i0 = brev(bi, 5);
+            s = (lane >> 5) | (wave << 1);
+            base = ((size_t)brev0(blk0 + s, A.log_n - 8) << 8) + (bi << 3);
+#pragma unroll
+            for (int m = 0; m < 8; m++) load_elem32(e[m], A.x + (base + br3(m)) * 8);
+        } else {
+            s = lane & 7;
+            i0 = (lane >> 3) | (wave << 3);
+            base = (size_t)(blk0 + s) + (size_t)i0 * S;
+            step = (size_t)32 * S;
+#pragma unroll
+            for (int m = 0; m < 8; m++) load_elem32(e[m], A.x + (base + m * step) * 8);
+        }
+    }
+    __syncthreads(); // s_tw complete
+
+    {
+        TwV<Fr> t;
+        // round 0: pairs (m, m + 4), twiddle index i0 + 32 m
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            load_tw2(t, s_tw, i0 + 32 * m);
+            bfly<Fr, PL.b[0], true, PL.red[0], false>(e[m], e[m + 4], t.w, t.q);
+        }
+        // round 1: pairs (m, m + 2), twiddle index 2 (i0 + 32 (m & 1))
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            load_tw2(t, s_tw, 2 * (i0 + 32 * h));
+            bfly<Fr, PL.b[1], true, PL.red[1], false>(e[h], e[h + 2], t.w, t.q);
+            bfly<Fr, PL.b[1], true, PL.red[1], false>(e[h + 4], e[h + 6], t.w, t.q);
+        }
+        // round 2: pairs (m, m + 1), twiddle index 4 i0
+        load_tw2(t, s_tw, 4 * i0);
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[2], true, PL.red[2], false>(e[m], e[m + 1], t.w, t.q);
+    }
+
+    // ---- exchange 1: element (s, i) lives at word s | ((i[7:5] ^ i[1:0]) << 3) | (i[4:0] << 6) of each plane
+    {
+        unsigned wa[8];
+        const unsigned wbase = s | ((i0 & 3) << 3) | (i0 << 6);
+#pragma unroll
+        for (int m = 0; m < 8; m++) wa[m] = wbase ^ (m << 3);
+        // block B: thread (s, g, j0) holds i = 32 g + 4 m + j0; j0 is the wave
+        s = lane & 7;
+        const unsigned g = lane >> 3, j0 = wave;
+        const unsigned ra = s | ((g ^ j0) << 3) | (j0 << 6);
+        exchange<Fr, PB, 256>(e, s_x, wa, ra);
+    }
+
+    // ---- block B: rounds 3..5 (distances 16, 8, 4).  Twiddle indices 8 (4 (m & 3) + j0), 16 (4 (m & 1) + j0), 32 j0: wave-uniform
+    {
+        const unsigned j0 = wave;
+        TwV<Fr> t;
+        if (j0 == 0) { // twiddle 1 wherever the register bits below the round's own are clear
+            bfly<Fr, PL.b[3], false, PL.red[3], true>(e[0], e[4], nullptr, nullptr);
+#pragma unroll
+            for (int m = 1; m < 4; m++) {
+                load_tw2_uniform(t, A.pq, 32 * m);
+                bfly<Fr, PL.b[3], true, PL.red[3], true>(e[m], e[m + 4], t.w, t.q);
+            }
+            bfly<Fr, PL.b[4], false, PL.red[4], true>(e[0], e[2], nullptr, nullptr);
+            bfly<Fr, PL.b[4], false, PL.red[4], true>(e[4], e[6], nullptr, nullptr);
+            load_tw2_uniform(t, A.pq, 64);
+            bfly<Fr, PL.b[4], true, PL.red[4], true>(e[1], e[3], t.w, t.q);
+            bfly<Fr, PL.b[4], true, PL.red[4], true>(e[5], e[7], t.w, t.q);
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], false, PL.red[5], true>(e[m], e[m + 1], nullptr, nullptr);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
+                bfly<Fr, PL.b[3], true, PL.red[3], true>(e[m], e[m + 4], t.w, t.q);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                load_tw2_uniform(t, A.pq, 16 * (4 * h + j0));
+                bfly<Fr, PL.b[4], true, PL.red[4], true>(e[h], e[h + 2], t.w, t.q);
+                bfly<Fr, PL.b[4], true, PL.red[4], true>(e[h + 4], e[h + 6], t.w, t.q);
+            }
+            load_tw2_uniform(t, A.pq, 32 * j0);
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true>(e[m], e[m + 1], t.w, t.q);
+        }
+    }
+
+    // ---- exchange 2: element (s, i) lives at word b | (s << 5) | (i[2:0] << 8), b[1:0] = i[6:5] ^ i[4:3], b[4:2] = s ^ (i[7], i[4:3])
+    unsigned q;
+    {
+        __syncthreads(); // everyone has read exchange 1's last batch
+        unsigned wa[8];
+        const unsigned g = lane >> 3, j0 = wave; // s is still lane & 7
+        const unsigned wbase = (g & 3) | ((s ^ (g & 4)) << 2) | (s << 5) | (j0 << 8);
+#pragma unroll
+        for (int m = 0; m < 8; m++) wa[m] = (wbase ^ ((m >> 1) * 5)) + ((m & 1) << 10); // i[4:3] = m >> 1 enters both fields, i[2] = m & 1
+        // block C: thread (s, q) holds i = 8 q + m
+        if (A.br_out) {
+            q = lane & 31;
+            s = (lane >> 5) | (wave << 1);
+        } else if (lgp == 0) { // outputs i_out = bitrev8(8 q + m) = 32 bitrev3(m) + bitrev5(q) of one sub-transform are contiguous in i_out
+            q = brev(lane & 31, 5);
+            s = (lane >> 5) | (wave << 1);
+        } else { // consecutive sub-transforms are contiguous
+            s = lane & 7;
+            q = (lane >> 3) | (wave << 3);
+        }
+        const unsigned ra = (((q >> 2) ^ q) & 3) | ((s ^ (((q >> 4) << 2) | (q & 3))) << 2) | (s << 5);
+        exchange<Fr, PB, 256>(e, s_x, wa, ra);
+    }
+
+    // ---- block C: rounds 6, 7 (distances 2, 1).  Round 6: twiddle 1 for even i, the 4th root of unity w^64 for odd i; round 7: 1
+    {
+        TwV<Fr> t;
+        load_tw2_uniform(t, A.pq, 64);
+        bfly<Fr, PL.b[6], false, PL.red[6], true>(e[0], e[2], nullptr, nullptr);
+        bfly<Fr, PL.b[6], false, PL.red[6], true>(e[4], e[6], nullptr, nullptr);
+        bfly<Fr, PL.b[6], true, PL.red[6], true>(e[1], e[3], t.w, t.q);
+        bfly<Fr, PL.b[6], true, PL.red[6], true>(e[5], e[7], t.w, t.q);
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[7], false, PL.red[7], true, !PL.red[7]>(e[m], e[m + 1], nullptr, nullptr);
+    }
+    constexpr int FB = PL.b[8];
+    static_assert(FB < (int)Fr::HEADROOM && FB < 512, "final bound");
+
+    // ---- output: register m holds output i_out = 32 bitrev3(m) + bitrev5(q) of sub-transform blk = blk0 + s
+    const unsigned blk = blk0 + s;
+    const unsigned p = 1u << lgp, k = blk & (p - 1);
+    const unsigned iq = brev(q, 5);
+    if constexpr (LAST) {
+        size_t base;
+        if (A.br_out)
+            base = ((size_t)brev0(blk, lgp) << 8) + (q << 3);
+        else
+            base = ((size_t)(blk - k) << 8) + k + ((size_t)iq << lgp);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            fe_reduce_mad_2p(e[m]);
+            fe_reduce_once(e[m]);
+            const size_t dst = A.br_out ? base + m : base + ((size_t)(br3(m) << 5) << lgp);
+            store_elem32(A.y + dst * 8, e[m]);
+        }
+    } else {
+        const size_t base = ((size_t)(blk - k) << 8) + k + ((size_t)iq << lgp);
+        const unsigned i2 = (blk >> lgp) >> A.i2_shift;
+        if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
+            const unsigned row = i2 << A.ca;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                TwV<Fr> t;
+                load_tw2(t, A.ta, row | ((br3(m) << 5) | iq));
+                Fe<Fr> v;
+                fe_mul_shoup<Fr, false>(v, e[m], t.w, t.q);
+                store_elem32(A.y + (base + ((size_t)(br3(m) << 5) << lgp)) * 8, v);
+            }
+        } else { // k2 = i_out 2^lgp + k: the low ca (<= lgp) bits are the thread's, the rest the element's
+            TwV<Fr> ta;
+            load_tw2(ta, A.ta, (i2 << A.ca) | (k & ((1u << A.ca) - 1)));
+            const unsigned rowb = i2 << A.cb, khi0 = k >> A.ca, sh = lgp - A.ca;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                TwV<Fr> t;
+                load_tw2(t, A.tb, rowb | ((((br3(m) << 5) | iq) << sh) | khi0));
+                Fe<Fr> v, u;
+                fe_mul_shoup<Fr, false>(u, e[m], t.w, t.q);
+                fe_mul_shoup<Fr, false>(v, u, ta.w, ta.q);
+                store_elem32(A.y + (base + ((size_t)(br3(m) << 5) << lgp)) * 8, v);
+            }
+        }
+    }
+}
+
+} // namespace panda_ntt8

@@ -84,7 +84,58 @@ static void chain(u32 *r, const u32 *bases, const unsigned char *neg, size_t n, 
         xyzz_to_jacobian_wire(r, acc);
 }
 
+// raw 29-bit-limb interface to the precomputed-quotient product: x any limbs within the contract, w in internal form
+template <class F>
+static void shoup(u32 *r, u32 *tw_out, const u32 *x, const u32 *w_internal, size_t n)
+{
+    constexpr int N = F::N;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> xe, we, re;
+        for (int j = 0; j < N; j++) {
+            xe.l[j] = x[i * N + j];
+            we.l[j] = w_internal[i * N + j];
+        }
+        FeTw<F> t;
+        fe_shoup_prepare(t, we);
+        fe_mul_shoup(re, xe, t);
+        for (int j = 0; j < N; j++) {
+            r[i * N + j] = re.l[j];
+            tw_out[i * 2 * N + j] = t.w[j];
+            tw_out[i * 2 * N + N + j] = t.q[j];
+        }
+    }
+}
+template <class F>
+static void reduce_mad(u32 *r, const u32 *x, size_t n)
+{
+    constexpr int N = F::N;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> xe;
+        for (int j = 0; j < N; j++) xe.l[j] = x[i * N + j];
+        fe_reduce_mad_2p(xe);
+        for (int j = 0; j < N; j++) r[i * N + j] = xe.l[j];
+    }
+}
+
 extern "C" {
+int h29_shoup(int field_id, u32 *r, u32 *tw_out, const u32 *x, const u32 *w_internal, size_t n)
+{
+    switch (field_id) {
+    case 1: shoup<Bn254Fr>(r, tw_out, x, w_internal, n); return 0;
+    case 3: shoup<Bls377Fr>(r, tw_out, x, w_internal, n); return 0;
+    case 5: shoup<Bls381Fr>(r, tw_out, x, w_internal, n); return 0;
+    }
+    return 1;
+}
+int h29_reduce_mad(int field_id, u32 *r, const u32 *x, size_t n)
+{
+    switch (field_id) {
+    case 1: reduce_mad<Bn254Fr>(r, x, n); return 0;
+    case 3: reduce_mad<Bls377Fr>(r, x, n); return 0;
+    case 5: reduce_mad<Bls381Fr>(r, x, n); return 0;
+    }
+    return 1;
+}
 int h29_field_op(int field_id, int op, u32 *r, const u32 *a, const u32 *b, size_t n)
 {
     switch (field_id) {

@@ -139,3 +139,67 @@ def test_k13_all_equal_bases_chain(h29, golden_dir):
     h29.h29_chain(0, _p(out), _p(bases), None, C.c_size_t(n), 0)
     c = pyref.CURVES[0]
     assert (po.to_affine(0, out) == pyref.encode_affine(c, pyref.ec_mul(c, n, c.g))).all()
+
+
+@pytest.mark.parametrize("fid", [1, 3, 5])
+def test_precomputed_quotient_product(h29, fid):
+    """fe_mul_shoup / fe_shoup_prepare (the NTT's twiddle products): x * w - q * p is congruent to x * w, tight, below
+    (x / R + 2) p, for operands at the edge of the limb contract (limbs up to 2^31 + 2^24, values up to 8 R); the stored
+    quotient is floor(w R / p).  The column accumulators are shadowed in 128 bits inside the library (FE29_CHECK)."""
+    info = po.field_info(fid)
+    mod = pyref.limbs_to_int(info["p"])
+    N, W = 9, 29
+    R = 1 << (W * N)
+    rng = np.random.default_rng(900 + fid)
+    n = 4000
+    limb_max = (1 << 31) + (1 << 24) - 1
+    x = rng.integers(0, 1 << 29, size=(n, N), dtype=np.uint64)
+    x[n // 4: n // 2] = rng.integers(0, limb_max + 1, size=(n // 4, N), dtype=np.uint64)  # raw differences
+    x[n // 2: n // 2 + 50] = limb_max                                                        # every column at its maximum
+    x[n // 2 + 50: n // 2 + 100] = 0
+    x[:, N - 1] = np.minimum(x[:, N - 1], (1 << 32) - 1)
+    x = x.astype(np.uint32)
+    ws = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2] + [int.from_bytes(rng.bytes(40), "little") % mod for _ in range(n - 6)]
+    w_int = np.array([[((w * R % mod) >> (W * j)) & ((1 << W) - 1) if j < N - 1 else (w * R % mod) >> (W * (N - 1)) for j in range(N)] for w in ws], dtype=np.uint32)
+    r = np.empty((n, N), dtype=np.uint32)
+    tw = np.empty((n, 2 * N), dtype=np.uint32)
+    assert h29.h29_shoup(fid, _p(r), _p(tw), _p(x), _p(w_int), C.c_size_t(n)) == 0
+    for i in range(n):
+        X = sum(int(x[i, j]) << (W * j) for j in range(N))
+        got = sum(int(r[i, j]) << (W * j) for j in range(N))
+        assert all(int(r[i, j]) < (1 << W) for j in range(N))
+        assert got % mod == X * ws[i] % mod
+        assert got < (X // R + 3) * mod
+        assert sum(int(tw[i, j]) << (W * j) for j in range(N)) == ws[i]
+        assert sum(int(tw[i, N + j]) << (W * j) for j in range(N)) == ws[i] * R // mod
+
+
+@pytest.mark.parametrize("fid", [1, 3, 5])
+def test_multiply_add_reduction(h29, fid):
+    """fe_reduce_mad_2p: raw limbs (< 2^32), value below 2^9 p -> tight, same residue, below 2p."""
+    info = po.field_info(fid)
+    mod = pyref.limbs_to_int(info["p"])
+    N, W = 9, 29
+    rng = np.random.default_rng(950 + fid)
+    n = 4000
+    x = np.zeros((n, N), dtype=np.uint32)
+    vals = []
+    for i in range(n):
+        k = int(rng.integers(0, 512))
+        v = k * mod + int.from_bytes(rng.bytes(40), "little") % mod if i % 7 else k * mod + (mod - 1 if i % 2 else 0)
+        v = min(v, 512 * mod - 1)
+        # a random carry-free limb decomposition with limbs up to 2^32 - 1: move multiples of 2^29 downwards
+        l = [(v >> (W * j)) & ((1 << W) - 1) for j in range(N - 1)] + [v >> (W * (N - 1))]
+        for j in range(N - 1, 0, -1):
+            t = min(int(rng.integers(0, 8)), l[j])
+            l[j] -= t
+            l[j - 1] += t << W
+        assert all(0 <= a < (1 << 32) for a in l) and sum(a << (W * j) for j, a in enumerate(l)) == v
+        x[i] = l
+        vals.append(v)
+    r = np.empty_like(x)
+    assert h29.h29_reduce_mad(fid, _p(r), _p(x), C.c_size_t(n)) == 0
+    for i in range(n):
+        got = sum(int(r[i, j]) << (W * j) for j in range(N))
+        assert all(int(r[i, j]) < (1 << W) for j in range(N))
+        assert got % mod == vals[i] % mod and got < 2 * mod
