@@ -47,6 +47,19 @@ MAD_PEAK_PER_S = 28.45e12
 # multiply-adds of one XYZZ mixed addition on 9 x 29-bit limbs: 8 products of 162, 2 squarings of 126, one shared reduction
 # (counted in the ISA of k_accumulate<Bn254Fq>)
 MADS_PER_ADDITION_BN254 = 1467
+# the same count for a 14-limb base field (BLS12-377 / BLS12-381): 8 * 2 * 14^2 + 2 * (14 * 15 / 2 + 14^2) - 14^2
+MADS_PER_ADDITION = {0: 1467, 1: 3542, 2: 3542}
+# Operation-count MODEL of the reference's CUDA MSM on this chip: per call
+# n * W * 11 mulmods of Jacobian mixed additions (msm_cuda.cuh:373-409) + B * ~370 for weighting and reducing the B = W (2^c - 1)
+# buckets (msm_cuda.cuh:411-449, 451-497) at its fixed c = 16, W = 16, priced at the measured rate of the reference's own kind of
+# multiplication on gfx950: 8 x 32-bit CIOS Montgomery, 92.58 G mulmod/s at 8 waves per SIMD (profiles/r01_ubench_int_rates.txt,
+# "montmul8x32").  A model, not a measurement: the reference cannot run here (no CUDA device) and publishes no number.
+REF_MODEL_MULMOD_PER_S = 92.58e9
+
+
+def reference_model_ms(log_n: int) -> float:
+    n, w, c = 1 << log_n, 16, 16
+    return (n * w * 11 + w * ((1 << c) - 1) * 370) / REF_MODEL_MULMOD_PER_S * 1e3
 SEED = 0x70616E6461
 
 
@@ -284,6 +297,12 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT[0] * n, "kernel_ms": acc_kernel_ms},
             "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
         }
+        if world == 1:
+            ref_ms = reference_model_ms(log_n)
+            out["vs_reference_model"] = {"value": ref_ms / (dt / args.steps * 1e3), "kind": "model", "reference_model_ms": ref_ms,
+                                         "model": "reference CUDA algorithm's mulmod count at c = 16 (n W 11 + W (2^c - 1) 370, SURVEY 8a row a19; msm_cuda.cuh:373-497) "
+                                                  "priced at the measured 8x32-bit Montgomery rate on this chip (92.58 G mulmod/s, profiles/r01_ubench_int_rates.txt) "
+                                                  "divided by ms_per_step -- not a measurement of the reference, which cannot run without a CUDA device"}
         if windows:
             # what actually bounds k_accumulate: every sorted entry is one XYZZ mixed addition; a digit is zero
             # with probability 2^-c, so W * n additions per launch to within 1e-6 for random scalars
@@ -295,12 +314,16 @@ def main():
                                      "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s (a sub-millisecond launch at the nominal "
                                                     "2.4 GHz; this kernel sustains ~2.0 GHz at ~1240 W, profiles/r02_accumulate_stalls.txt)"}
 
+    failed = []
+
     def leg(name, fn):
-        """Secondary figures never take the contract line down with them: a failure is reported in place of the number."""
+        """Secondary figures never take the contract line down with them: a failure is reported in place of the number, the
+        line is still printed, and the process then exits non-zero."""
         try:
             res = fn()
         except Exception as e:  # noqa: BLE001
             res = {"error": repr(e)[:300]}
+            failed.append(name)
         if rank == 0 and res is not None:
             out[name] = res
 
@@ -319,16 +342,21 @@ def main():
             leg("ntt_sharded", lambda: ntt_sharded_figure(ctx))
     if world == 1 and not args.no_extra_configs:
         leg("config2_msm_2_20", lambda: small_config(ctx, 0, 20, ctx.ffi.JACOBIAN, 20, "BN254 MSM 2^20, Jacobian output, cached bases (BASELINE config 2)"))
+        leg("msm_2_22", lambda: small_config(ctx, 0, 22, ctx.ffi.JACOBIAN, 10, "BN254 MSM 2^22, Jacobian output, cached bases (north_star sweep 2^20 ... 2^26)"))
         leg("config5_bls12_377_2_24_projective",
             lambda: small_config(ctx, 1, 24, ctx.ffi.PROJECTIVE, 5, "BLS12-377 MSM 2^24 + Projective-output conversion (BASELINE config 5)"))
         leg("bn254_g2_msm_2_20", lambda: small_config(ctx, 3, 20, ctx.ffi.JACOBIAN, 5, "BN254 G2 MSM 2^20 (SURVEY 8f-4; coordinates in Fq2), Jacobian output, cached bases"))
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         leg("cpu_baseline", lambda: cpu_baseline(args.cpu_sample_log_n))
     if rank == 0:
+        if failed:
+            out["failed_legs"] = failed
         print(json.dumps(out), flush=True)
     if world > 1:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
+    if failed:
+        raise SystemExit(f"bench.py: secondary leg(s) failed: {failed}")
 
 
 def config4(ctx: Ctx, total_log_n: int) -> dict:
@@ -365,9 +393,24 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
         ph = prob.phases()
         res[label] = {"value": prob.n / dt, "ms_per_step": dt * 1e3, "bases": prob.mode, "k_accumulate_ms": ph[3], "device_ms": ph[7],
                       "roofline_frac_hbm": BYTES_PER_POINT[curve] * prob.n / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if curve in MADS_PER_ADDITION and ph[3] > 0:
+            # the bound that binds: one mixed addition per sorted entry -- W n with tables, windows * n without
+            additions = (prob.tables if prob.tables > 1 else plain_windows(curve, log_n)) * prob.n
+            mads = additions * MADS_PER_ADDITION[curve] / (ph[3] * 1e-3)
+            res[label]["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12, "unit": "T mad lane-ops/s",
+                                            "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions, "mads_per_addition": MADS_PER_ADDITION[curve]}
+    if curve == 0:
+        res["vs_reference_model"] = {"value": reference_model_ms(log_n) / res["with_tables"]["ms_per_step"], "kind": "model", "reference_model_ms": reference_model_ms(log_n)}
     res["value"] = res["with_tables"]["value"]
     prob.release()
     return res
+
+
+def plain_windows(curve: int, log_n: int) -> int:
+    """windows of the plain (no tables) path: c = clamp(log_n - 4, 4, 16) bits (pick_window_bits, csrc/msm.hip) over the scalar field's bits"""
+    c = min(max(log_n - 4, 4), 16)
+    bits = {0: 254, 1: 253, 2: 255, 3: 254}[curve]
+    return -(-bits // c)
 
 
 def without_tables(ctx: Ctx, prob: MsmProblem, steps: int) -> dict:
@@ -436,8 +479,8 @@ def pcie_inclusive(ctx: Ctx, prob: MsmProblem) -> dict:
     return out
 
 
-def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
-    """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident, median of `reps`."""
+def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
+    """forward and inverse BN254 NTT of 2^log_n device-resident elements, median of `reps`"""
     torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
     n = 1 << log_n
     a = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
@@ -467,13 +510,23 @@ def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
     fwd, fwd_wall = timed(lib.panda_ntt_execute_bn254_v1)
     inv, inv_wall = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
-    return {"metric": "NTT elements/s (BN254 Fr, 2^24, forward)", "value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3,
-            "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv, "forward_plus_inverse_ms": (fwd + inv) * 1e3,
-            "forward_plus_inverse_elements_per_s": n / (fwd + inv),
-            "timing": "ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); wall_ms = host time of the synchronous call",
-            "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3,
+    del a, b
+    torch.cuda.empty_cache()
+    return {"value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3, "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv,
+            "forward_plus_inverse_ms": (fwd + inv) * 1e3, "forward_plus_inverse_elements_per_s": n / (fwd + inv),
+            "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3, "passes": -(-log_n // 8),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
+
+
+def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
+    """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26."""
+    res = ntt_one(ctx, log_n, reps)
+    res["metric"] = "NTT elements/s (BN254 Fr, 2^24, forward)"
+    res["timing"] = ("ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); "
+                     "wall_ms = host time of the synchronous call")
+    res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 5) for k in (20, 22, 26)}
+    return res
 
 
 def ntt_sharded_figure(ctx: Ctx, reps: int = 5) -> dict:

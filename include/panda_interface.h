@@ -182,7 +182,8 @@ panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, uns
  * on h2d_stream while range r runs digits -> sort -> accumulate on exec_cfg.stream against its own rows of the registered tables; each
  * range's buckets are added into a running total on the device, which is reduced once.  Unregistered bases, or fewer than 2^16 points
  * in the first range, reduce the number of ranges, down to one copy followed by the ordinary call.  h_scalars == NULL skips the copies
- * and runs the same schedule on resident scalars.  Synchronous on return like panda_msm_execute_*; same group element.  curve: 0 / 1 / 2. */
+ * and runs the same schedule on resident scalars.  Synchronous on return like panda_msm_execute_*; same group element.  curve: 0 .. 3
+ * (BN254, BLS12-377, BLS12-381, BN254 G2). */
 panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configuration exec_cfg, const void *h_scalars, unsigned ranges, panda_stream h2d_stream);
 
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
@@ -246,6 +247,34 @@ panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuratio
  * inverse transform).  cfg.omega is the FORWARD root.  Enqueued without waiting, flag valid on return. */
 panda_error panda_ntt_slab_inverse_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_inverse_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
+
+/* Multi-GPU, ONE process (no reference counterpart: msm_cuda.cuh:554-555 pins device 0, wrapper.rs:38 opens one
+ * device, binding.rs:54-56 only declares the peer-access symbols).  A panda_multi_gpu owns one host thread, one stream and -- with
+ * PANDA_MULTI_RCCL -- one RCCL communicator per device (ncclCommInitAll); the whole sharded operation is one call:
+ *   panda_msm_execute_*_multi   cfgs[d] is an ordinary panda_msm_configuration whose buffers live on devices[d] and describe that
+ *                               device's base-point range (stream.handle == NULL: the handle's own stream of that device).  Every device
+ *                               runs the single-GPU pipeline on its worker thread and leaves its JACOBIAN partial in cfgs[d].results;
+ *                               one ncclAllGather moves the partials, the sum in cfgs[0]'s coordinate type goes to `result` (HOST, 96 /
+ *                               144 bytes).  Synchronous on return.
+ *   panda_ntt_execute_*_multi   cfgs[d] is the slab configuration of rank d (rank == d, log_ranks == log2(n_dev), a power of two):
+ *                               step 1 on every device, ONE grouped ncclSend / ncclRecv all-to-all (chunk q of rank d to rank q), step 2
+ *                               on every device, one synchronisation at the end.  *cfgs[d].flag (HOST) = 1 if rank d's output sits in
+ *                               its d_scratch, 0 if in its d_slab.  Layouts as for the panda_ntt_slab_* halves above.
+ * PANDA_MULTI_LOOPBACK replaces RCCL by device-to-device copies and lets one device play several ranks (tests on a one-GPU box; also
+ * what a caller without xGMI peers gets).  The worker threads keep the library's per-thread scratch and twiddle caches alive between
+ * calls; per-device setup (allocation, panda_msm_precompute_bases) is done by the caller under panda_set_device(devices[d]). */
+typedef struct panda_multi_gpu { void *handle; } panda_multi_gpu;
+#define PANDA_MULTI_RCCL 0u
+#define PANDA_MULTI_LOOPBACK 1u
+panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, unsigned n_dev, unsigned transport);
+panda_error panda_multi_gpu_destroy(panda_multi_gpu mg);
+panda_error panda_multi_gpu_device_count(panda_multi_gpu mg, unsigned *n_dev);
+panda_error panda_msm_execute_bn254_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs /* n_dev */, void *result /* host */);
+panda_error panda_msm_execute_bls12_377_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result);
+panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* n_dev */);
+panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
+/* per-phase device times of rank's last MSM inside a *_multi call (the workers' panda_msm_last_phase_ms) */
+panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms /* PANDA_MSM_PHASES floats */);
 
 /* Synthetic inputs generated on the device; curve: 0 = BN254, 1 = BLS12-377, 2 = BLS12-381, 3 = BN254 G2 */
 panda_error panda_gen_scalars(unsigned curve, uint64_t seed, uint64_t first, uint64_t n, void *d_out, panda_stream stream);

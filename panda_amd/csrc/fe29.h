@@ -664,6 +664,19 @@ __device__ inline __attribute__((always_inline)) void fe29_shoup_lo_cols(uint64_
 {
     (fe29_shoup_lo_col<F, UNIFORM, C>(acc, x, w, q, out), ...);
 }
+template <class F, bool UNIFORM, int... C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_hi_cols_x2(uint64_t &a0, uint64_t &a1, const uint32_t *x0, const uint32_t *x1, const uint32_t *wq0,
+                                                                            const uint32_t *wq1, uint32_t *q0, uint32_t *q1, std::integer_sequence<int, C...>)
+{
+    ((fe29_shoup_hi_col<F, UNIFORM, F::N - 2 + C>(a0, x0, wq0, q0), fe29_shoup_hi_col<F, UNIFORM, F::N - 2 + C>(a1, x1, wq1, q1)), ...);
+}
+template <class F, bool UNIFORM, int... C>
+__device__ inline __attribute__((always_inline)) void fe29_shoup_lo_cols_x2(uint64_t &a0, uint64_t &a1, const uint32_t *x0, const uint32_t *x1, const uint32_t *w0,
+                                                                            const uint32_t *w1, const uint32_t *q0, const uint32_t *q1, uint32_t *o0, uint32_t *o1,
+                                                                            std::integer_sequence<int, C...>)
+{
+    ((fe29_shoup_lo_col<F, UNIFORM, C>(a0, x0, w0, q0, o0), fe29_shoup_lo_col<F, UNIFORM, C>(a1, x1, w1, q1, o1)), ...);
+}
 #endif
 
 // r = x * w - q * p.  UNIFORM: the constant is the same in every lane of the wave and sits in scalar registers.
@@ -726,6 +739,34 @@ template <class F, bool UNIFORM = false>
 PANDA_HD void fe_mul_shoup(Fe<F> &r, const Fe<F> &x, const FeTw<F> &t)
 {
     fe_mul_shoup<F, UNIFORM>(r, x, t.w, t.q);
+}
+
+// Two independent products with their columns interleaved: r0 = x0 * (w0, wq0), r1 = x1 * (w1, wq1).  A column is a dependent chain
+// of multiply-adds (one wave alone issues them at 40 % of the instruction's rate), and hipcc puts a wait state between an asm block
+// and the next instruction that reads its result; alternating the columns of two products gives every chain an independent
+// neighbour, which removes both.
+template <class F, bool UNIFORM = false>
+PANDA_HD void fe_mul_shoup_x2(Fe<F> &r0, Fe<F> &r1, const Fe<F> &x0, const Fe<F> &x1, const u32 *w0, const u32 *wq0, const u32 *w1, const u32 *wq1)
+{
+#if defined(FE29_DEVICE_CHAINS)
+    constexpr int N = F::N;
+    static_assert(RawOperandOk<F>::value, "no column headroom for a raw operand in this field");
+    u32 q0[N], q1[N], o0[N], o1[N];
+    u64 a0 = 0, a1 = 0;
+    fe29_shoup_hi_cols_x2<F, UNIFORM>(a0, a1, x0.l, x1.l, wq0, wq1, q0, q1, std::make_integer_sequence<int, N + 1>());
+    q0[N - 1] = (u32)a0 & LIMB_MASK;
+    q1[N - 1] = (u32)a1 & LIMB_MASK;
+    a0 = a1 = 0;
+    fe29_shoup_lo_cols_x2<F, UNIFORM>(a0, a1, x0.l, x1.l, w0, w1, q0, q1, o0, o1, std::make_integer_sequence<int, N>());
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        r0.l[i] = o0[i];
+        r1.l[i] = o1[i];
+    }
+#else
+    fe_mul_shoup<F, UNIFORM>(r0, x0, w0, wq0);
+    fe_mul_shoup<F, UNIFORM>(r1, x1, w1, wq1);
+#endif
 }
 
 // (w, floor(w R / p)) from w in internal form (w R mod p, tight, < 2p).  w R = k p + (w R mod p) with k the quotient wanted, so

@@ -242,17 +242,22 @@ PandaGpuError panda_msm_bn254_gpu_with_cached_bases(const PandaGpuManager &gm, B
         // additive: upload and execution pipelined inside the one call -- the scalars cross PCIe in point ranges on the
         // h2d stream while the previous range is being accumulated on the exec stream (panda_msm_execute_from_host)
         const size_t result_buf_len = FIELD_ELEMENT_LEN * 3;
-        void *d_scalars = nullptr, *d_result = nullptr;
-        PandaGpuError e = malloc_from_pool_async(&d_scalars, ((size_t)1 << log_n) * FIELD_ELEMENT_LEN, gm.get_mem_pool(), gm.get_h2d_stream());
+        struct Buffers { // freed on every way out of this block
+            void *d_scalars = nullptr, *d_result = nullptr;
+            ~Buffers()
+            {
+                if (d_scalars) (void)panda_free(d_scalars);
+                if (d_result) (void)panda_free(d_result);
+            }
+        } b;
+        PandaGpuError e = malloc_from_pool_async(&b.d_scalars, ((size_t)1 << log_n) * FIELD_ELEMENT_LEN, gm.get_mem_pool(), gm.get_h2d_stream());
         if (e != PandaGpuError::Ok) return e;
-        if ((e = malloc_from_pool_async(&d_result, result_buf_len, gm.get_mem_pool(), gm.get_h2d_stream())) != PandaGpuError::Ok) return e;
+        if ((e = malloc_from_pool_async(&b.d_result, result_buf_len, gm.get_mem_pool(), gm.get_h2d_stream())) != PandaGpuError::Ok) return e;
         if ((e = gm.wait_h2d()) != PandaGpuError::Ok) return e;
-        panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_bases, d_scalars, d_result, log_n, gm.get_msm_result_coordinate_type()};
+        panda_msm_configuration cfg{gm.get_mem_pool(), gm.get_exec_stream(), d_bases, b.d_scalars, b.d_result, log_n, gm.get_msm_result_coordinate_type()};
         const bool ran = panda_msm_execute_from_host(0, cfg, scalars.data, ranges, gm.get_h2d_stream()) == 0;
         result->resize(result_buf_len);
-        const bool copied = ran && panda_memcpy(result->data(), d_result, result_buf_len) == 0;
-        (void)panda_free(d_scalars);
-        (void)panda_free(d_result);
+        const bool copied = ran && panda_memcpy(result->data(), b.d_result, result_buf_len) == 0;
         return !ran ? PandaGpuError::SchedulingErr : (copied ? PandaGpuError::Ok : PandaGpuError::CreateContextError);
     }
     void *d_scalars = nullptr;

@@ -122,7 +122,9 @@ thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 // panda_free_async drop every entry whose buffer lies in the allocation being freed, and for buffers freed behind the
 // library's back (a caching allocator such as torch's) each entry keeps REG_SAMPLES rows of the wire buffer as it was
 // at registration: every execute compares them on the device and, on a mismatch, forgets the entry and runs the call
-// again from the caller's buffer, so a recycled address can never serve another base set's tables.
+// again from the caller's buffer.  The comparison is a SAMPLE (REG_SAMPLES rows): a recycled address whose new content differs
+// from the old one in unsampled rows only is not detected -- callers that recycle device buffers behind the library's back
+// should unregister first; panda_free / panda_free_async do it for them.
 struct RegisteredBases : panda::MsmRegistration {
     RegisteredBases() : panda::MsmRegistration{} {}
     RegisteredBases(const RegisteredBases &) = delete;
@@ -216,16 +218,25 @@ hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, co
     }
 }
 
+// bytes of one affine base / one result on the wire (2 / 3 coordinates of L 32-bit limbs; G2 coordinates are pairs)
+constexpr size_t kAffineBytes[4] = {64, 96, 96, 128};
+constexpr size_t kResultBytes[4] = {96, 144, 144, 192};
+
 hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmPipeline *pipe = nullptr)
 {
     if (cfg.log_scalars_count > 26 || !cfg.bases) return hipErrorInvalidValue;
+    // buffers shorter than log_scalars_count implies are refused here instead of faulting in a kernel
+    const size_t n = (size_t)1 << cfg.log_scalars_count;
+    if (panda::extent_too_short(cfg.bases, n * kAffineBytes[curve]) || panda::extent_too_short(cfg.scalars, n * 32) ||
+        panda::extent_too_short(cfg.results, kResultBytes[curve]))
+        return hipErrorInvalidValue;
     const RegisteredPtr reg = lookup_registered(cfg.bases, cfg.log_scalars_count, curve); // held for the whole call
     bool stale = false;
     hipError_t e = msm_execute_on(curve, cfg, reg.get(), &stale, pipe);
     if (e == hipSuccess && stale) {
         // the buffer no longer holds the bases it held when it was registered (freed and reallocated behind our back):
         // the entry is dropped and the call answered from the caller's buffer as it is now
-        printf("[panda-hip] registered bases at %p changed since registration: registration dropped, converting per call\n", cfg.bases);
+        fprintf(stderr, "[panda-hip] registered bases at %p changed since registration: registration dropped, converting per call\n", cfg.bases);
         const RegisteredBases *gone = reg.get();
         forget_if([gone](const RegisteredBases &r) { return &r == gone; });
         e = msm_execute_on(curve, cfg, nullptr, nullptr, pipe);
@@ -236,6 +247,7 @@ hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg, const
 hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, bool tabled, unsigned window_bits, hipStream_t s)
 {
     if (curve > 3 || !d_bases || log_n > 26) return hipErrorInvalidValue;
+    if (panda::extent_too_short(d_bases, ((size_t)1 << log_n) * kAffineBytes[curve])) return hipErrorInvalidValue;
     const unsigned fr = panda::msm_scalar_field_of(curve);
     if (const RegisteredPtr have = lookup_registered(d_bases, log_n, curve)) {
         if (!tabled && !have->tabled) return hipSuccess;
@@ -260,6 +272,9 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
               : curve == 2 ? panda::msm_build_registration_bls381(*r, s)
                            : panda::msm_build_registration_bn254_g2(*r, s));
     std::lock_guard<std::mutex> lock(g_registry_mutex);
+    // another host thread may have registered the same buffer while this one was building its tables: keep the first, drop ours
+    for (const auto &have : g_registry)
+        if (have->wire == d_bases && have->log_n == log_n && have->curve == curve && have->device == r->device) return hipSuccess;
     g_registry.push_back(std::move(r));
     g_registry_count.store(g_registry.size(), std::memory_order_release);
     return hipSuccess;

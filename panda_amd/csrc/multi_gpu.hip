@@ -1,0 +1,364 @@
+// multi_gpu.hip -- the sharded MSM and NTT behind ONE C call, for a host that is not Python: one process, one host thread per
+// device, RCCL over xGMI for the exchange ("one process, 8 devices, one ncclComm_t per device via
+// ncclCommInitAll"; north_star: "Rust host code calling HIP through the existing C-ABI").  The reference has no counterpart -- it
+// pins device 0 (src/cuda/core/unit/msm/msm_cuda.cuh:554-555, src/gpu_manager/wrapper.rs:38) and only declares the peer-access
+// symbols (src/gpu_ffi/binding.rs:54-56).
+//
+//   MSM   shards by base-point range: device d runs the ordinary panda_msm_execute_* on its range (its own worker thread, so its own
+//         scratch arena); the Jacobian partials (96 / 144 B each) are all-gathered with one ncclAllGather and added up on the host
+//         (panda_msm_combine_*: EC addition is not an RCCL reduction operator).
+//   NTT   shards by decimated slab: panda_ntt_slab_step1 on every device, ONE grouped ncclSend / ncclRecv all-to-all (chunk q of
+//         rank d goes to rank q; every GPU pair has its own xGMI link, so this is not a ring), panda_ntt_slab_step2 on every device.
+//         Everything is enqueued on the per-device streams; the call synchronises once at the end.
+//
+// Worker threads live as long as the handle: the library's scratch arenas and twiddle caches are per host thread, so a prover that
+// repeats the same sharded call launches kernels only.
+//
+// PANDA_MULTI_LOOPBACK replaces RCCL by device-to-device copies and allows one device to play several ranks: the same threads,
+// flags and chunk arithmetic as the RCCL path, testable on a one-GPU box (tests/test_gpu_parity.py, manager_test.cpp).
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "panda_internal.h"
+
+namespace {
+
+constexpr size_t MAX_RESULT_BYTES = 192; // BN254 G2 Jacobian
+
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<hipError_t()> job;
+    bool has_job = false, done = false, stop = false;
+    hipError_t result = hipSuccess;
+    int device = 0;
+
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<hipError_t()> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this] { return has_job || stop; });
+                if (stop) break;
+                j = std::move(job);
+                has_job = false;
+            }
+            hipError_t e = j();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                result = e;
+                done = true;
+            }
+            cv.notify_all();
+        }
+        // the thread's scratch arena and twiddle caches are released by their thread_local destructors
+    }
+    void submit(std::function<hipError_t()> j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            has_job = true;
+            done = false;
+        }
+        cv.notify_all();
+    }
+    hipError_t wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return done; });
+        return result;
+    }
+};
+
+struct MultiGpu {
+    unsigned n = 0;
+    unsigned transport = PANDA_MULTI_RCCL;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;                 // used when a configuration carries no stream of its own
+    std::vector<void *> d_gather;                     // per device: n x MAX_RESULT_BYTES, partials of every rank
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<float> phase_ms;                      // n x PANDA_MSM_PHASES, from the workers' last MSM
+    std::mutex call_mutex;                            // one sharded call at a time per handle
+
+    template <class Fn>
+    hipError_t on_all(Fn fn) // fn(rank) on every worker, with its device current; first error wins
+    {
+        for (unsigned d = 0; d < n; d++) workers[d]->submit([fn, d] { return fn(d); });
+        hipError_t first = hipSuccess;
+        for (unsigned d = 0; d < n; d++) {
+            hipError_t e = workers[d]->wait();
+            if (first == hipSuccess) first = e;
+        }
+        return first;
+    }
+    ~MultiGpu()
+    {
+        for (auto &w : workers) {
+            if (!w) continue;
+            {
+                std::lock_guard<std::mutex> lk(w->m);
+                w->stop = true;
+            }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+        for (unsigned d = 0; d < comms.size(); d++)
+            if (comms[d]) (void)ncclCommDestroy(comms[d]);
+        for (unsigned d = 0; d < n && d < devices.size(); d++) {
+            (void)hipSetDevice(devices[d]);
+            if (d < streams.size() && streams[d]) (void)hipStreamDestroy(streams[d]);
+            if (d < d_gather.size() && d_gather[d]) (void)hipFree(d_gather[d]);
+        }
+    }
+};
+
+hipError_t from_nccl(ncclResult_t r, const char *what)
+{
+    if (r == ncclSuccess) return hipSuccess;
+    printf("[panda-hip] RCCL error in %s: %s\n", what, ncclGetErrorString(r));
+    return hipErrorUnknown;
+}
+#define PANDA_TRY_NCCL(expr) PANDA_TRY(from_nccl((expr), #expr))
+
+hipStream_t stream_of(const MultiGpu &mg, unsigned d, panda_stream s) { return s.handle ? static_cast<hipStream_t>(s.handle) : mg.streams[d]; }
+
+hipError_t sync_all(MultiGpu &mg, const std::vector<hipStream_t> &streams)
+{
+    for (unsigned d = 0; d < mg.n; d++) {
+        PANDA_TRY(hipSetDevice(mg.devices[d]));
+        PANDA_TRY(hipStreamSynchronize(streams[d]));
+    }
+    return hipSuccess;
+}
+
+typedef panda_error (*msm_fn)(const panda_msm_configuration);
+typedef panda_error (*combine_fn)(const void *, unsigned, panda_msm_result_coordinate_type, void *);
+
+hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *result, size_t rb, msm_fn execute, combine_fn combine)
+{
+    if (!cfgs || !result) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> call(mg.call_mutex);
+    int caller_dev = 0;
+    PANDA_TRY(hipGetDevice(&caller_dev));
+    std::vector<hipStream_t> streams(mg.n);
+    for (unsigned d = 0; d < mg.n; d++) streams[d] = stream_of(mg, d, cfgs[d].stream);
+    // every device: the ordinary single-GPU call on its base range (synchronous), then its partial into slot d of its gather buffer
+    hipError_t e = mg.on_all([&](unsigned d) -> hipError_t {
+        panda_msm_configuration c = cfgs[d];
+        c.msm_result_coordinate_type = JACOBIAN; // partials are added as Jacobian points; the requested form is produced by the combine
+        c.stream.handle = streams[d];
+        const panda_error pe = execute(c);
+        if (pe != panda_success) return static_cast<hipError_t>(pe);
+        (void)panda_msm_last_phase_ms(&mg.phase_ms[d * PANDA_MSM_PHASES]);
+        return hipMemcpyAsync((char *)mg.d_gather[d] + d * rb, c.results, rb, hipMemcpyDefault, streams[d]);
+    });
+    if (e == hipSuccess) {
+        if (mg.transport == PANDA_MULTI_RCCL) {
+            // one collective: every device ends with all partials (in place: the send buffer is the rank's own slot)
+            e = [&]() -> hipError_t {
+                PANDA_TRY_NCCL(ncclGroupStart());
+                for (unsigned d = 0; d < mg.n; d++)
+                    PANDA_TRY_NCCL(ncclAllGather((char *)mg.d_gather[d] + d * rb, mg.d_gather[d], rb, ncclChar, mg.comms[d], streams[d]));
+                PANDA_TRY_NCCL(ncclGroupEnd());
+                return hipSuccess;
+            }();
+        } else {
+            e = sync_all(mg, streams);
+            for (unsigned d = 0; e == hipSuccess && d < mg.n; d++) {
+                e = hipSetDevice(mg.devices[d]);
+                for (unsigned q = 0; e == hipSuccess && q < mg.n; q++)
+                    if (q != d) e = hipMemcpyAsync((char *)mg.d_gather[d] + q * rb, (char *)mg.d_gather[q] + q * rb, rb, hipMemcpyDefault, streams[d]);
+            }
+        }
+    }
+    if (e == hipSuccess) e = sync_all(mg, streams);
+    if (e == hipSuccess) {
+        std::vector<unsigned char> partials(mg.n * rb);
+        e = hipSetDevice(mg.devices[0]);
+        if (e == hipSuccess) e = hipMemcpy(partials.data(), mg.d_gather[0], mg.n * rb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = static_cast<hipError_t>(combine(partials.data(), mg.n, cfgs[0].msm_result_coordinate_type, result));
+    }
+    (void)hipSetDevice(caller_dev);
+    return e;
+}
+
+typedef panda_error (*slab_fn)(const panda_ntt_slab_configuration);
+
+// forward: step1 -> all-to-all -> step2; inverse: inverse_step1 -> the same all-to-all -> inverse_step2
+hipError_t ntt_multi(MultiGpu &mg, const panda_ntt_slab_configuration *cfgs, slab_fn first, slab_fn second)
+{
+    if (!cfgs) return hipErrorInvalidValue;
+    unsigned log_ranks = 0;
+    while ((1u << log_ranks) < mg.n) log_ranks++;
+    if ((1u << log_ranks) != mg.n) return hipErrorInvalidValue; // the slab decomposition wants a power of two
+    for (unsigned d = 0; d < mg.n; d++)
+        if (cfgs[d].rank != d || cfgs[d].log_ranks != log_ranks || cfgs[d].log_n != cfgs[0].log_n || cfgs[d].log_n < 2 * log_ranks || !cfgs[d].d_slab ||
+            !cfgs[d].d_scratch || !cfgs[d].omega)
+            return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> call(mg.call_mutex);
+    int caller_dev = 0;
+    PANDA_TRY(hipGetDevice(&caller_dev));
+    const size_t slab_bytes = (size_t)32 << (cfgs[0].log_n - log_ranks), chunk = slab_bytes >> log_ranks;
+    std::vector<hipStream_t> streams(mg.n);
+    std::vector<unsigned> flag(mg.n, 0);
+    std::vector<char *> src(mg.n), dst(mg.n);
+    for (unsigned d = 0; d < mg.n; d++) streams[d] = stream_of(mg, d, cfgs[d].stream);
+    hipError_t e = mg.on_all([&](unsigned d) -> hipError_t {
+        panda_ntt_slab_configuration c = cfgs[d];
+        c.stream.handle = streams[d];
+        c.flag = &flag[d];
+        return static_cast<hipError_t>(first(c)); // enqueued; the flag is valid on return
+    });
+    if (e == hipSuccess) {
+        for (unsigned d = 0; d < mg.n; d++) {
+            src[d] = (char *)(flag[d] ? cfgs[d].d_scratch : cfgs[d].d_slab);
+            dst[d] = (char *)(flag[d] ? cfgs[d].d_slab : cfgs[d].d_scratch);
+        }
+        if (mg.transport == PANDA_MULTI_RCCL) {
+            // the single exchange: chunk q of rank d -> chunk d of rank q, all pairs in one group (full mesh, one xGMI link per pair)
+            e = [&]() -> hipError_t {
+                PANDA_TRY_NCCL(ncclGroupStart());
+                for (unsigned d = 0; d < mg.n; d++)
+                    for (unsigned q = 0; q < mg.n; q++) {
+                        PANDA_TRY_NCCL(ncclSend(src[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], streams[d]));
+                        PANDA_TRY_NCCL(ncclRecv(dst[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], streams[d]));
+                    }
+                PANDA_TRY_NCCL(ncclGroupEnd());
+                return hipSuccess;
+            }();
+        } else {
+            e = sync_all(mg, streams); // every rank's step 1 is complete before anybody copies out of it
+            for (unsigned d = 0; e == hipSuccess && d < mg.n; d++) {
+                e = hipSetDevice(mg.devices[d]);
+                for (unsigned q = 0; e == hipSuccess && q < mg.n; q++)
+                    e = hipMemcpyAsync(dst[d] + q * chunk, src[q] + d * chunk, chunk, hipMemcpyDefault, streams[d]);
+            }
+        }
+    }
+    if (e == hipSuccess)
+        e = mg.on_all([&](unsigned d) -> hipError_t {
+            panda_ntt_slab_configuration c = cfgs[d];
+            c.stream.handle = streams[d];
+            c.d_slab = dst[d];
+            c.d_scratch = src[d];
+            c.flag = &flag[d];
+            const panda_error pe = second(c);
+            if (pe != panda_success) return static_cast<hipError_t>(pe);
+            return hipStreamSynchronize(streams[d]);
+        });
+    if (e == hipSuccess)
+        for (unsigned d = 0; d < mg.n; d++) {
+            const char *out = flag[d] ? src[d] : dst[d];
+            if (cfgs[d].flag) *(unsigned *)cfgs[d].flag = out == (const char *)cfgs[d].d_scratch ? 1u : 0u;
+        }
+    (void)hipSetDevice(caller_dev);
+    return e;
+}
+
+MultiGpu *handle_of(panda_multi_gpu mg) { return static_cast<MultiGpu *>(mg.handle); }
+
+} // namespace
+
+extern "C" {
+
+panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, unsigned n_dev, unsigned transport)
+{
+    if (!out || !devices || n_dev == 0 || n_dev > 64 || transport > PANDA_MULTI_LOOPBACK) return panda_error_invalid_value;
+    int count = 0, caller_dev = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&caller_dev) != hipSuccess) return panda_error_invalid_value;
+    for (unsigned d = 0; d < n_dev; d++) {
+        if (devices[d] < 0 || devices[d] >= count) return panda_error_invalid_value;
+        if (transport == PANDA_MULTI_RCCL)
+            for (unsigned q = 0; q < d; q++)
+                if (devices[q] == devices[d]) return panda_error_invalid_value; // one RCCL rank per device
+    }
+    std::unique_ptr<MultiGpu> mg(new MultiGpu());
+    mg->n = n_dev;
+    mg->transport = transport;
+    mg->devices.assign(devices, devices + n_dev);
+    mg->streams.assign(n_dev, nullptr);
+    mg->d_gather.assign(n_dev, nullptr);
+    mg->phase_ms.assign((size_t)n_dev * PANDA_MSM_PHASES, 0.f);
+    hipError_t e = hipSuccess;
+    for (unsigned d = 0; e == hipSuccess && d < n_dev; d++) {
+        e = hipSetDevice(devices[d]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->streams[d], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&mg->d_gather[d], (size_t)n_dev * MAX_RESULT_BYTES);
+    }
+    if (e == hipSuccess && transport == PANDA_MULTI_RCCL) {
+        mg->comms.assign(n_dev, nullptr);
+        e = from_nccl(ncclCommInitAll(mg->comms.data(), (int)n_dev, devices), "ncclCommInitAll");
+    }
+    (void)hipSetDevice(caller_dev);
+    if (e != hipSuccess) return static_cast<panda_error>(e);
+    for (unsigned d = 0; d < n_dev; d++) {
+        mg->workers.emplace_back(new Worker());
+        Worker *w = mg->workers.back().get();
+        w->device = devices[d];
+        w->th = std::thread([w] { w->loop(); });
+    }
+    out->handle = mg.release();
+    return panda_success;
+}
+
+panda_error panda_multi_gpu_destroy(panda_multi_gpu mg)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    int caller_dev = 0;
+    (void)hipGetDevice(&caller_dev);
+    delete handle_of(mg);
+    (void)hipSetDevice(caller_dev);
+    return panda_success;
+}
+
+panda_error panda_multi_gpu_device_count(panda_multi_gpu mg, unsigned *n_dev)
+{
+    if (!mg.handle || !n_dev) return panda_error_invalid_value;
+    *n_dev = handle_of(mg)->n;
+    return panda_success;
+}
+
+panda_error panda_msm_execute_bn254_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(msm_multi(*handle_of(mg), cfgs, result, 96, panda_msm_execute_bn254, panda_msm_combine_bn254));
+}
+
+panda_error panda_msm_execute_bls12_377_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(msm_multi(*handle_of(mg), cfgs, result, 144, panda_msm_execute_bls12_377, panda_msm_combine_bls12_377));
+}
+
+panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(ntt_multi(*handle_of(mg), cfgs, panda_ntt_slab_step1_bn254_enqueue, panda_ntt_slab_step2_bn254_enqueue));
+}
+
+panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        ntt_multi(*handle_of(mg), cfgs, panda_ntt_slab_inverse_step1_bn254_enqueue, panda_ntt_slab_inverse_step2_bn254_enqueue));
+}
+
+panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms)
+{
+    if (!mg.handle || !ms || rank >= handle_of(mg)->n) return panda_error_invalid_value;
+    for (int i = 0; i < PANDA_MSM_PHASES; i++) ms[i] = handle_of(mg)->phase_ms[(size_t)rank * PANDA_MSM_PHASES + i];
+    return panda_success;
+}
+
+} // extern "C"

@@ -503,17 +503,39 @@ struct TwiddleCache {
     bool valid = false;
     u32 key[12] = {0};
     // tables enqueued by a call that did not wait for its stream (the *_enqueue entry points) are complete only in that
-    // stream's order: a later call on another stream waits for it first
-    hipStream_t pending = nullptr;
+    // stream's order.  The enqueueing call records an event behind them; the next call makes ITS stream wait for that event --
+    // no host wait, and no handle of the earlier stream is kept (the caller may have destroyed it since).
+    hipEvent_t pending_ev = nullptr;
+    int pending_dev = -1;
     bool has_pending = false;
+    hipError_t mark_pending(hipStream_t s)
+    {
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (pending_ev && pending_dev != dev) {
+            (void)hipEventDestroy(pending_ev);
+            pending_ev = nullptr;
+        }
+        if (!pending_ev) {
+            if ((e = hipEventCreateWithFlags(&pending_ev, hipEventDisableTiming)) != hipSuccess) return e;
+            pending_dev = dev;
+        }
+        if ((e = hipEventRecord(pending_ev, s)) != hipSuccess) return e;
+        has_pending = true;
+        return hipSuccess;
+    }
     hipError_t settle(hipStream_t next)
     {
-        if (has_pending && pending != next) {
-            hipError_t e = hipStreamSynchronize(pending);
-            if (e != hipSuccess) return e;
-        }
-        if (has_pending && pending != next) has_pending = false;
-        return hipSuccess;
+        if (!has_pending) return hipSuccess;
+        has_pending = false; // whatever happens below, the next call starts clean
+        return hipStreamWaitEvent(next, pending_ev, 0);
+    }
+    void drop_pending()
+    {
+        has_pending = false;
+        if (pending_ev) (void)hipEventDestroy(pending_ev);
+        pending_ev = nullptr;
     }
     hipError_t ensure(size_t bytes)
     {
@@ -548,6 +570,7 @@ struct TwiddleCache {
     TwiddleCache &operator=(const TwiddleCache &) = delete;
     ~TwiddleCache()
     {
+        drop_pending();
         if (base) (void)hipFree(base); // a host thread that exits without panda_ntt_tear_down() does not leak its tables
     }
     hipError_t release()
@@ -560,6 +583,7 @@ struct TwiddleCache {
         base = nullptr;
         capacity = used = 0;
         valid = false;
+        drop_pending();
         return e;
     }
 };
@@ -737,6 +761,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
                    bool br_out = false)
 {
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
+    if (panda::extent_too_short(d_src, (size_t)32 << log_n) || panda::extent_too_short(d_dst, (size_t)32 << log_n)) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
     TwiddleCache &tw = g_twiddles[TW_WHOLE];
     u32 key[12];
@@ -795,6 +820,7 @@ template <class Fr>
 hipError_t ntt_coset_run(const panda_ntt_configuration_v1 &cfg, const void *shift_wire, bool inverse)
 {
     if (!shift_wire || !cfg.d_src || !cfg.d_dst || !cfg.d_omega || !cfg.flag || cfg.log_n > 28) return hipErrorInvalidValue;
+    if (panda::extent_too_short(cfg.d_src, (size_t)32 << cfg.log_n) || panda::extent_too_short(cfg.d_dst, (size_t)32 << cfg.log_n)) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     Fe<Fr> g;
     fe_from_wire(g, (const u32 *)shift_wire);
@@ -811,16 +837,21 @@ hipError_t ntt_coset_run(const panda_ntt_configuration_v1 &cfg, const void *shif
     return scale_by_powers<Fr>(stream, res, cfg.log_n, gi);
 }
 
+// a rank's slab and scratch hold 2^(log_n - log_ranks) elements each (log_n >= log_ranks checked by the callers)
+bool slab_too_short(const panda_ntt_slab_configuration &cfg)
+{
+    const size_t bytes = (size_t)32 << (cfg.log_n - cfg.log_ranks);
+    return panda::extent_too_short(cfg.d_slab, bytes) || panda::extent_too_short(cfg.d_scratch, bytes);
+}
+
 // shared tail of the two slab steps: publish the tables in the cache, optionally wait
 hipError_t slab_finish(TwiddleCache &tw, const u32 (&key)[12], hipStream_t stream, bool wait)
 {
     if (wait) {
         PANDA_TRY(hipStreamSynchronize(stream));
         tw.has_pending = false;
-    } else {
-        tw.pending = stream;
-        tw.has_pending = true;
-    }
+    } else
+        PANDA_TRY(tw.mark_pending(stream));
     memcpy(tw.key, key, sizeof(tw.key));
     tw.valid = true;
     return hipSuccess;
@@ -834,6 +865,7 @@ hipError_t slab_step1(const panda_ntt_slab_configuration &cfg, bool wait)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
     if (cfg.rank >= (1u << cfg.log_ranks)) return hipErrorInvalidValue;
+    if (slab_too_short(cfg)) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     PANDA_TRY(order_after_null_stream(stream));
     const unsigned log_m = cfg.log_n - cfg.log_ranks;
@@ -882,6 +914,7 @@ template <class Fr>
 hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait, bool inverse = false)
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < 2 * cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
+    if (slab_too_short(cfg)) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     PANDA_TRY(order_after_null_stream(stream));
     const unsigned log_m = cfg.log_n - cfg.log_ranks;
@@ -941,6 +974,7 @@ hipError_t slab_inverse_local(const panda_ntt_slab_configuration &cfg, bool wait
 {
     if (cfg.log_ranks > 8 || cfg.log_n > 28 || cfg.log_n < cfg.log_ranks || !cfg.d_slab || !cfg.d_scratch || !cfg.omega) return hipErrorInvalidValue;
     if (cfg.rank >= (1u << cfg.log_ranks)) return hipErrorInvalidValue;
+    if (slab_too_short(cfg)) return hipErrorInvalidValue;
     hipStream_t stream = static_cast<hipStream_t>(cfg.stream.handle);
     PANDA_TRY(order_after_null_stream(stream));
     const unsigned log_m = cfg.log_n - cfg.log_ranks;

@@ -59,4 +59,22 @@ void registry_forget_allocation(const void *ptr);
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Boundary check for caller buffers: true when `ptr` lies in an allocation the runtime can describe and that allocation ends
+// before ptr + bytes.  A caller that passes a buffer shorter than log_n implies (round 2: a 4 KB buffer with log_n = 10 on a
+// 128-byte-per-point curve) would otherwise make a kernel read past it and take the process down; with this the entry point
+// answers panda_error_invalid_value.  Pointers the runtime does not know (host memory, other allocators' sub-ranges it cannot
+// resolve) pass: the check can only ever refuse what is provably too short.
+static inline bool extent_too_short(const void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void *>(ptr)) != hipSuccess || !base || !size) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t off = (size_t)((const char *)ptr - (const char *)base);
+    return off > size || size - off < bytes;
+}
+
 } // namespace panda

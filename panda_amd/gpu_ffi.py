@@ -53,6 +53,13 @@ class NttconfigurationV1(C.Structure):  # gpu_ffi/common.rs:198-208
                 ("omega", C.c_void_p), ("log_n", C.c_uint), ("flag", C.POINTER(C.c_uint))]
 
 
+class PandaMultiGpu(C.Structure):  # additive: include/panda_interface.h panda_multi_gpu (one process, one worker thread + RCCL communicator per device)
+    _fields_ = [("handle", C.c_void_p)]
+
+
+MULTI_RCCL, MULTI_LOOPBACK = 0, 1
+
+
 class NttSlabConfiguration(C.Structure):  # additive: include/panda_interface.h panda_ntt_slab_configuration
     _fields_ = [("stream", PandaStream), ("d_slab", C.c_void_p), ("d_scratch", C.c_void_p), ("omega", C.c_void_p),
                 ("log_n", C.c_uint), ("log_ranks", C.c_uint), ("rank", C.c_uint), ("flag", C.POINTER(C.c_uint))]
@@ -75,6 +82,8 @@ ADDITIVE_SYMBOLS = [
     "panda_msm_combine_bls12_377", "panda_msm_setup_bn254_g2", "panda_msm_execute_bn254_g2", "panda_msm_execute_bn254_g2_host", "panda_msm_combine_bn254_g2", "panda_msm_setup_bls12_381", "panda_msm_execute_bls12_381", "panda_msm_execute_bls12_381_host", "panda_msm_combine_bls12_381",
     "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_ntt_slab_inverse_step1_bn254_enqueue", "panda_ntt_slab_inverse_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
     "panda_debug_field_op", "panda_debug_curve_op", "panda_version",
+    "panda_multi_gpu_create", "panda_multi_gpu_destroy", "panda_multi_gpu_device_count", "panda_msm_execute_bn254_multi", "panda_msm_execute_bls12_377_multi",
+    "panda_ntt_execute_bn254_multi", "panda_ntt_execute_bn254_inverse_multi", "panda_multi_gpu_last_phase_ms",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
 
@@ -129,6 +138,11 @@ def load() -> C.CDLL:
         "panda_ntt_slab_inverse_step1_bn254_enqueue": [NttSlabConfiguration], "panda_ntt_slab_inverse_step2_bn254_enqueue": [NttSlabConfiguration],
         "panda_gen_scalars": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream], "panda_gen_bases": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream],
         "panda_debug_field_op": [u, u, vp, vp, vp, sz, PandaStream], "panda_debug_curve_op": [u, u, vp, vp, vp, sz, PandaStream],
+        "panda_multi_gpu_create": [C.POINTER(PandaMultiGpu), C.POINTER(C.c_int), u, u], "panda_multi_gpu_destroy": [PandaMultiGpu],
+        "panda_multi_gpu_device_count": [PandaMultiGpu, C.POINTER(u)],
+        "panda_msm_execute_bn254_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp], "panda_msm_execute_bls12_377_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp],
+        "panda_ntt_execute_bn254_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)], "panda_ntt_execute_bn254_inverse_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)],
+        "panda_multi_gpu_last_phase_ms": [PandaMultiGpu, u, C.POINTER(C.c_float)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

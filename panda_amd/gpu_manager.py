@@ -296,17 +296,19 @@ def panda_msm_bn254_gpu_with_cached_bases(gm: PandaGpuManager, scalars, bases_in
     if d_bases in gm._registered and chunks > 1:
         lib = ffi.load()
         nres = _RESULT_BYTES[curve]
-        d_scalars = _pool_alloc(gm, (1 << log_n) * FIELD_ELEMENT_LEN, gm.h2d_stream)
-        d_result = _pool_alloc(gm, nres, gm.h2d_stream)
-        gm.wait_h2d()
-        cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d_bases, d_scalars, d_result, log_n, gm.msm_result_coordinate_type)
-        try:
+        d_scalars = d_result = None
+        try:  # both buffers go back on every way out, including a failed second allocation or wait
+            d_scalars = _pool_alloc(gm, (1 << log_n) * FIELD_ELEMENT_LEN, gm.h2d_stream)
+            d_result = _pool_alloc(gm, nres, gm.h2d_stream)
+            gm.wait_h2d()
+            cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, d_bases, d_scalars, d_result, log_n, gm.msm_result_coordinate_type)
             ffi.check(lib.panda_msm_execute_from_host(curve, cfg, _ptr(s), chunks, gm.h2d_stream.raw), "SchedulingErr")
             out = np.zeros(nres, dtype=np.uint8)
             ffi.check(lib.panda_memcpy(_ptr(out), C.c_void_p(d_result), nres), "CreateContextError")
         finally:
-            lib.panda_free(C.c_void_p(d_scalars))
-            lib.panda_free(C.c_void_p(d_result))
+            for d in (d_scalars, d_result):
+                if d is not None:
+                    lib.panda_free(C.c_void_p(d))
         return out
     d_scalars = memory_alloc_and_copy(gm, s, gm.h2d_stream)
     gm.wait_h2d()

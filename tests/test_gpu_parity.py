@@ -964,6 +964,33 @@ def test_msm_ragged_lengths_and_bad_arguments(gm):
     flag = C.c_uint(0)
     bad = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, None, d.ptr, None, 4, C.pointer(flag))
     assert lib.panda_ntt_execute_bn254_v1(bad) == 1
+    # Buffers shorter than log_n implies are refused at the boundary instead of being read past their end.  The first line is the
+    # call that took the process down in round 2: 2^10 G2 points are 128 KiB, the buffer has 4 KiB.
+    assert lib.panda_msm_precompute_bases(3, d.ptr, 10, 0, gm.exec_stream.raw) == 1
+    assert lib.panda_msm_register_bases(0, d.ptr, 10, gm.exec_stream.raw) == 1
+    big = DeviceBuffer(1 << 20)
+    om = po.root_of_unity(po.F_BN254_FR, 10)
+    for b, s_, r in ((d, big, big), (big, d, big)):  # bases / scalars too short for 2^10 points
+        cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, b.ptr, s_.ptr, r.ptr, 10, pgm.JACOBIAN)
+        assert lib.panda_msm_execute_bn254(cfg) == 1
+        assert lib.panda_msm_execute_bls12_377(cfg) == 1
+    short_result = C.c_void_p(big.ptr.value + (1 << 20) - 64)  # 64 bytes left in the allocation, a result needs 96
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, big.ptr, big.ptr, short_result, 10, pgm.JACOBIAN)
+    assert lib.panda_msm_execute_bn254(cfg) == 1
+    for src, dst in ((d, big), (big, d)):  # 2^10 elements are 32 KiB
+        cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, src.ptr, dst.ptr, C.c_void_p(om.ctypes.data), 10, C.pointer(flag))
+        assert lib.panda_ntt_execute_bn254_v1(cfg) == 1
+        assert lib.panda_ntt_execute_bn254_inverse(cfg) == 1
+    slab = ffi.NttSlabConfiguration(gm.exec_stream.raw, d.ptr, big.ptr, C.c_void_p(om.ctypes.data), 12, 1, 0, C.pointer(flag))  # slab of 2^11
+    assert lib.panda_ntt_slab_step1_bn254(slab) == 1
+    # ... and buffers of exactly the right size are accepted (the check is not off by one)
+    exact_b, exact_s, exact_r = DeviceBuffer(64 << 10), DeviceBuffer(32 << 10), DeviceBuffer(96)
+    ffi.check(lib.panda_gen_bases(0, 77, 0, 1 << 10, exact_b.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(0, 78, 0, 1 << 10, exact_s.ptr, NULL_STREAM), "gen")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, exact_b.ptr, exact_s.ptr, exact_r.ptr, 10, pgm.JACOBIAN)
+    assert lib.panda_msm_execute_bn254(cfg) == 0
+    for b in (big, exact_b, exact_s, exact_r):
+        b.free()
     d.free()
 
 

@@ -11,11 +11,12 @@ typedef Bn254Fr F;
 #define ITERS 256
 // VARIANT 0: x = x * w (Montgomery)      1: shoup, w per lane      2: shoup, w per wave
 //         3: butterfly, Montgomery       4: butterfly, shoup per lane   5: butterfly, shoup per wave
+//         6: x2-interleaved products, w per lane     7: two butterflies per iteration with x2-interleaved products, w per lane     8: the same, w per wave
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in, const u32 *tw)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    Fe<F> x, z, w;
+    Fe<F> x, z, w, x2, z2;
     FeTw<F> t;
     for (int j = 0; j < 9; j++) {
         x.l[j] = in[(i & 1023) * 18 + j] & LIMB_MASK;
@@ -23,7 +24,10 @@ __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in, const u32 
     }
     x.l[8] &= 0x1fffff;
     z.l[8] &= 0x1fffff;
-    const int ti = (VARIANT == 2 || VARIANT == 5) ? (blockIdx.x & 63) : (i & 63);
+    x2 = z;
+    z2 = x;
+    x2.l[0] ^= 1;
+    const int ti = (VARIANT == 2 || VARIANT == 5 || VARIANT == 8) ? (blockIdx.x & 63) : (i & 63);
     for (int j = 0; j < 9; j++) {
         t.w[j] = tw[ti * 20 + j];
         t.q[j] = tw[ti * 20 + 9 + j];
@@ -39,6 +43,27 @@ __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in, const u32 
         } else if (VARIANT == 2) {
             fe_mul_shoup<F, true>(x, x, t);
             fe_mul_shoup<F, true>(z, z, t);
+        } else if (VARIANT == 6) {
+            fe_mul_shoup_x2<F, false>(x, z, x, z, t.w, t.q, t.w, t.q);
+        } else if (VARIANT == 7 || VARIANT == 8) {
+            // (x, z) and (z2, x2) are two independent butterflies
+            Fe<F> s0, s1, r0, r1;
+            fe_add(s0, x, z);
+            fe_sub_raw<F, 4>(r0, x, z);
+            fe_add(s1, x2, z2);
+            fe_sub_raw<F, 4>(r1, x2, z2);
+            if (VARIANT == 7)
+                fe_mul_shoup_x2<F, false>(z, z2, r0, r1, t.w, t.q, t.w, t.q);
+            else
+                fe_mul_shoup_x2<F, true>(z, z2, r0, r1, t.w, t.q, t.w, t.q);
+            for (int j = 0; j < 9; j++) {
+                s0.l[j] &= LIMB_MASK;
+                s1.l[j] &= LIMB_MASK;
+            }
+            s0.l[8] &= 0x1fffff;
+            s1.l[8] &= 0x1fffff;
+            x = s0;
+            x2 = s1;
         } else {
             Fe<F> s, d, raw;
             fe_add(s, x, z);
@@ -57,7 +82,7 @@ __global__ void __launch_bounds__(256) k_mul(u32 *out, const u32 *in, const u32 
         }
     }
     u32 sum = 0;
-    for (int j = 0; j < 9; j++) sum += x.l[j] * 3 + z.l[j] * 7;
+    for (int j = 0; j < 9; j++) sum += x.l[j] * 3 + z.l[j] * 7 + x2.l[j] * 11 + z2.l[j] * 13;
     out[i] = sum;
 }
 
@@ -76,10 +101,10 @@ static void run(const char *name, int blocks, u32 *out, u32 *in, u32 *tw)
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= 3;
-    const double muls = (double)blocks * 256 * ITERS * (V < 3 ? 2 : 1);
+    const double muls = (double)blocks * 256 * ITERS * ((V < 3 || V >= 6) ? 2 : 1);
     u32 chk;
     hipMemcpy(&chk, out, 4, hipMemcpyDeviceToHost);
-    printf("%-28s blocks=%5d  %8.3f ms  %8.2f G %s/s  (check %08x)\n", name, blocks, ms, muls / (ms * 1e-3) * 1e-9, V < 3 ? "mulmod" : "butterflies", chk);
+    printf("%-28s blocks=%5d  %8.3f ms  %8.2f G %s/s  (check %08x)\n", name, blocks, ms, muls / (ms * 1e-3) * 1e-9, (V < 3 || V == 6) ? "mulmod" : "butterflies", chk);
 }
 
 int main()
@@ -104,7 +129,7 @@ int main()
         }
     }
     hipMemcpy(tw, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
-    for (int wps : {2, 3, 4, 6, 8}) {
+    for (int wps : {1, 2, 3, 4}) {
         int blocks = 256 * wps;
         printf("--- %d waves/SIMD ---\n", wps);
         run<0>("montgomery", blocks, out, in, tw);
@@ -113,6 +138,9 @@ int main()
         run<3>("butterfly montgomery", blocks, out, in, tw);
         run<4>("butterfly shoup per lane", blocks, out, in, tw);
         run<5>("butterfly shoup per wave", blocks, out, in, tw);
+        run<6>("shoup x2 (w per lane)", blocks, out, in, tw);
+        run<7>("2 butterflies, x2 per lane", blocks, out, in, tw);
+        run<8>("2 butterflies, x2 per wave", blocks, out, in, tw);
     }
     return 0;
 }
