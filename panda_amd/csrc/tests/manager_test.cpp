@@ -218,6 +218,99 @@ int main(int argc, char **argv)
         REQUIRE(a == x);
         printf("NTT log_n = %u round trip ok\n", log_n);
     }
+    { // one process, every device of the box, through the C entry points a Rust host would bind (panda_*_multi, csrc/multi_gpu.hip): RCCL
+      // transport over the largest power-of-two number of devices (one on a one-GPU box), then the loopback transport with four ranks on
+      // device 0.  MSM total vs the single-device call; sharded NTT vs the single-device transform, and back through the inverse.
+        int count = 0;
+        REQUIRE(panda_get_device_number(&count) == 0 && count >= 1);
+        unsigned g_rccl = 1;
+        while (g_rccl * 2 <= (unsigned)count && g_rccl < 8) g_rccl *= 2;
+        for (int pass = 0; pass < 2; pass++) {
+            const unsigned G = pass == 0 ? g_rccl : 4;
+            const unsigned transport = pass == 0 ? PANDA_MULTI_RCCL : PANDA_MULTI_LOOPBACK;
+            std::vector<int> devices(G);
+            for (unsigned d = 0; d < G; d++) devices[d] = pass == 0 ? (int)d : 0;
+            panda_multi_gpu mg{};
+            REQUIRE(panda_multi_gpu_create(&mg, devices.data(), G, transport) == 0);
+            unsigned log_g = 0;
+            while ((1u << log_g) < G) log_g++;
+            // ---- MSM 2^16: range d lives on devices[d]
+            const unsigned k = 16;
+            const size_t n = (size_t)1 << k, per = n / G;
+            std::vector<uint8_t> bases(n * 64), scalars(n * 32), whole, total(96);
+            std::vector<void *> db(G), ds(G), dr(G);
+            std::vector<panda_msm_configuration> cfgs(G);
+            for (unsigned d = 0; d < G; d++) {
+                REQUIRE(panda_set_device(devices[d]) == 0);
+                REQUIRE(panda_malloc(&db[d], per * 64) == 0 && panda_malloc(&ds[d], per * 32) == 0 && panda_malloc(&dr[d], 96) == 0);
+                REQUIRE(panda_gen_bases(0, 4100, d * per, per, db[d], panda_stream{}) == 0);
+                REQUIRE(panda_gen_scalars(0, 4200, d * per, per, ds[d], panda_stream{}) == 0);
+                REQUIRE(panda_memcpy(bases.data() + d * per * 64, db[d], per * 64) == 0);
+                REQUIRE(panda_memcpy(scalars.data() + d * per * 32, ds[d], per * 32) == 0);
+                cfgs[d] = panda_msm_configuration{panda_mem_pool{}, panda_stream{}, db[d], ds[d], dr[d], k - log_g, JACOBIAN};
+            }
+            REQUIRE(panda_set_device(0) == 0);
+            REQUIRE(panda_msm_bn254_gpu(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &whole) == PandaGpuError::Ok);
+            for (int rep = 0; rep < 2; rep++) {
+                REQUIRE(panda_msm_execute_bn254_multi(mg, cfgs.data(), total.data()) == 0);
+                REQUIRE(affine_of(total, false) == affine_of(whole, false));
+            }
+            for (unsigned d = 0; d < G; d++) {
+                REQUIRE(panda_set_device(devices[d]) == 0);
+                REQUIRE(panda_free(db[d]) == 0 && panda_free(ds[d]) == 0 && panda_free(dr[d]) == 0);
+            }
+            // ---- NTT 2^14: rank d holds x[d + G j]
+            const unsigned log_n = 14;
+            const size_t nn = (size_t)1 << log_n, m = nn / G;
+            std::vector<uint8_t> x(nn * 32), y(nn * 32), slab(m * 32), got(nn * 32);
+            void *dx = nullptr;
+            REQUIRE(panda_set_device(0) == 0);
+            REQUIRE(panda_malloc(&dx, nn * 32) == 0);
+            REQUIRE(panda_gen_scalars(0, 4300, 0, nn, dx, panda_stream{}) == 0);
+            REQUIRE(panda_memcpy(x.data(), dx, nn * 32) == 0);
+            REQUIRE(panda_free(dx) == 0);
+            u32 omega[8];
+            root_of_unity(omega, log_n);
+            y = x;
+            REQUIRE(panda_ntt_bn254_gpu_v1(gm, y.data(), y.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+            std::vector<void *> d_slab(G), d_scr(G);
+            std::vector<unsigned> flags(G, 7);
+            std::vector<panda_ntt_slab_configuration> ncfg(G);
+            for (unsigned d = 0; d < G; d++) {
+                for (size_t j = 0; j < m; j++) memcpy(slab.data() + j * 32, x.data() + (d + G * j) * 32, 32);
+                REQUIRE(panda_set_device(devices[d]) == 0);
+                REQUIRE(panda_malloc(&d_slab[d], m * 32) == 0 && panda_malloc(&d_scr[d], m * 32) == 0);
+                REQUIRE(panda_memcpy(d_slab[d], slab.data(), m * 32) == 0);
+                ncfg[d] = panda_ntt_slab_configuration{panda_stream{}, d_slab[d], d_scr[d], omega, log_n, log_g, d, &flags[d]};
+            }
+            REQUIRE(panda_ntt_execute_bn254_multi(mg, ncfg.data()) == 0);
+            for (unsigned q = 0; q < G; q++) { // rank q holds y[k1 m + q m/G + k2'] at [k1][k2']
+                REQUIRE(flags[q] <= 1);
+                REQUIRE(panda_set_device(devices[q]) == 0);
+                REQUIRE(panda_memcpy(slab.data(), flags[q] ? d_scr[q] : d_slab[q], m * 32) == 0);
+                const size_t chunk = m / G;
+                for (unsigned k1 = 0; k1 < G; k1++) memcpy(got.data() + (k1 * m + q * chunk) * 32, slab.data() + k1 * chunk * 32, chunk * 32);
+            }
+            REQUIRE(got == y);
+            // inverse: from the output layout back to the decimated input slabs
+            for (unsigned d = 0; d < G; d++) {
+                void *out = flags[d] ? d_scr[d] : d_slab[d], *other = flags[d] ? d_slab[d] : d_scr[d];
+                ncfg[d].d_slab = out;
+                ncfg[d].d_scratch = other;
+            }
+            REQUIRE(panda_ntt_execute_bn254_inverse_multi(mg, ncfg.data()) == 0);
+            for (unsigned d = 0; d < G; d++) {
+                REQUIRE(panda_set_device(devices[d]) == 0);
+                REQUIRE(panda_memcpy(slab.data(), flags[d] ? ncfg[d].d_scratch : ncfg[d].d_slab, m * 32) == 0);
+                for (size_t j = 0; j < m; j++) REQUIRE(memcmp(slab.data() + j * 32, x.data() + (d + G * j) * 32, 32) == 0);
+                REQUIRE(panda_free(d_slab[d]) == 0 && panda_free(d_scr[d]) == 0);
+            }
+            REQUIRE(panda_set_device(0) == 0);
+            REQUIRE(panda_multi_gpu_destroy(mg) == 0);
+            printf("multi-GPU C entry points: %u rank(s), %s transport: MSM 2^16 and NTT 2^14 (forward + inverse) ok\n", G,
+                   transport == PANDA_MULTI_RCCL ? "RCCL" : "loopback");
+        }
+    }
     REQUIRE(gm.deinit() == PandaGpuError::Ok);
     printf("manager_test: all ok\n");
     return 0;

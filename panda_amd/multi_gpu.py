@@ -239,3 +239,56 @@ def ntt_sharded_one_process(slabs, scratches, omega, log_n: int, stream=None):
             flag = _slab_step(2, pstream, dst.data_ptr(), src.data_ptr(), om, log_n, g, q)
             outs.append(src if flag else dst)
     return outs
+
+
+# ------------------------------------------------------------------------------------------------ one process, C ABI (csrc/multi_gpu.hip)
+
+class MultiGpu:
+    """ctypes face of panda_multi_gpu: ONE process drives all devices through the C entry points (one worker thread, one stream and one
+    RCCL communicator per device inside the library) -- what a Rust / C host would call.  torch is not involved.
+
+        mg = MultiGpu([0, 1, 2, 3])                   # transport: ffi.MULTI_RCCL (default) or ffi.MULTI_LOOPBACK
+        total = mg.msm(cfgs, result_bytes=96)          # cfgs[d]: ffi.MSMConfiguration on devices[d]
+        flags = mg.ntt(slab_ptrs, scratch_ptrs, omega, log_n)
+    """
+
+    def __init__(self, devices, transport: int = ffi.MULTI_RCCL):
+        self.lib = ffi.load()
+        self.devices = list(devices)
+        self.n = len(self.devices)
+        self.handle = ffi.PandaMultiGpu()
+        arr = (C.c_int * self.n)(*self.devices)
+        ffi.check(self.lib.panda_multi_gpu_create(C.byref(self.handle), arr, self.n, transport), "CreateContextError")
+
+    def close(self):
+        if self.handle.handle:
+            self.lib.panda_multi_gpu_destroy(self.handle)
+            self.handle = ffi.PandaMultiGpu()
+
+    def msm(self, cfgs, curve: int = 0) -> np.ndarray:
+        """panda_msm_execute_*_multi: base ranges on the devices, one all-gather of partials, the total on the host."""
+        assert len(cfgs) == self.n and curve in (0, 1)
+        arr = (ffi.MSMConfiguration * self.n)(*cfgs)
+        out = np.zeros(96 if curve == 0 else 144, dtype=np.uint8)
+        fn = self.lib.panda_msm_execute_bn254_multi if curve == 0 else self.lib.panda_msm_execute_bls12_377_multi
+        ffi.check(fn(self.handle, arr, C.c_void_p(out.ctypes.data)), "SchedulingErr")
+        return out
+
+    def ntt(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None):
+        """panda_ntt_execute_bn254[_inverse]_multi on device pointers slabs[d] / scratches[d]; returns the flags (1: rank d's output is in
+        scratches[d])."""
+        assert len(slabs) == len(scratches) == self.n
+        g = _log2_exact(self.n)
+        om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+        flags = [C.c_uint(7) for _ in range(self.n)]
+        cfgs = (ffi.NttSlabConfiguration * self.n)(*[
+            ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[d]), C.c_void_p(scratches[d]), C.c_void_p(om.ctypes.data),
+                                     log_n, g, d, C.pointer(flags[d])) for d in range(self.n)])
+        fn = self.lib.panda_ntt_execute_bn254_inverse_multi if inverse else self.lib.panda_ntt_execute_bn254_multi
+        ffi.check(fn(self.handle, cfgs), "SchedulingErr")
+        return [f.value for f in flags]
+
+    def phases(self, rank: int):
+        ph = (C.c_float * 8)()
+        ffi.check(self.lib.panda_multi_gpu_last_phase_ms(self.handle, rank, ph), "SchedulingErr")
+        return list(ph)

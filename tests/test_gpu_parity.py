@@ -474,6 +474,99 @@ def test_msm_config4_partition_8_ranges_of_2_23(gm):
         assert (po.to_affine(0, partials[g]) == want).all()
 
 
+@pytest.mark.parametrize("ranks,transport", [(1, ffi.MULTI_RCCL), (1, ffi.MULTI_LOOPBACK), (4, ffi.MULTI_LOOPBACK), (8, ffi.MULTI_LOOPBACK)])
+def test_c_abi_multi_gpu_msm(gm, ranks, transport):
+    """panda_msm_execute_bn254_multi (csrc/multi_gpu.hip): base ranges, one worker thread per rank, partials gathered (ncclAllGather on
+    the RCCL transport -- one rank on this one-GPU box --, device copies on the loopback transport, where cuda:0 plays every rank) and
+    combined.  Total by linearity over all scalars, Jacobian and homogeneous; called twice (the workers' arenas are reused)."""
+    k = 16
+    n, per = 1 << k, (1 << k) // ranks
+    lib = ffi.load()
+    seed_b, seed_s = 0xC0DE + ranks, 0xFACE + ranks
+    db, ds = DeviceBuffer(n * 64), DeviceBuffer(n * 32)
+    results = [DeviceBuffer(96) for _ in range(ranks)]
+    ffi.check(lib.panda_gen_bases(0, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(0, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scalars = ds.to_host().reshape(n, 8)
+    want = po.expected_from_linearity(0, seed_b, scalars)
+    mg = multi_gpu.MultiGpu([0] * ranks, transport)
+    try:
+        for coord in (pgm.JACOBIAN, pgm.PROJECTIVE, pgm.JACOBIAN):
+            cfgs = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), C.c_void_p(db.ptr.value + r * per * 64), C.c_void_p(ds.ptr.value + r * per * 32),
+                                         results[r].ptr, k - (ranks.bit_length() - 1), coord) for r in range(ranks)]
+            total = mg.msm(cfgs)
+            assert (affine_of(0, total, coord) == want).all()
+        # each rank's buffer holds the Jacobian partial of its own range
+        r = ranks - 1
+        assert (po.to_affine(0, results[r].to_host()) == po.expected_from_linearity(0, seed_b, scalars[r * per:(r + 1) * per], first=r * per)).all()
+        assert mg.phases(r)[7] > 0
+        bad = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), None, ds.ptr, results[0].ptr, 4, pgm.JACOBIAN)] * ranks
+        with pytest.raises(ffi.PandaGpuError):
+            mg.msm(bad)  # a failing rank fails the call, the handle stays usable
+        assert (affine_of(0, mg.msm(cfgs), pgm.JACOBIAN) == want).all()
+    finally:
+        mg.close()
+        for d in [db, ds] + results:
+            d.free()
+
+
+@pytest.mark.parametrize("ranks,transport,log_n", [(1, ffi.MULTI_RCCL, 12), (2, ffi.MULTI_LOOPBACK, 9), (4, ffi.MULTI_LOOPBACK, 14), (8, ffi.MULTI_LOOPBACK, 21)])
+def test_c_abi_multi_gpu_ntt(gm, ranks, transport, log_n):
+    """panda_ntt_execute_bn254_multi / _inverse_multi: step 1 -> all-to-all -> step 2 behind one C call (grouped ncclSend / ncclRecv on
+    the RCCL transport, device copies on the loopback one); output layout and flags as for multi_gpu.ntt_sharded; forward vs the
+    oracle's plain transform, inverse back to the decimated input slabs."""
+    fid = po.F_BN254_FR
+    n = 1 << log_n
+    m = n // ranks
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 0x51AD + log_n, n)
+    slabs = [DeviceBuffer.from_host(multi_gpu.slab_of(x, ranks, r)) for r in range(ranks)]
+    scratches = [DeviceBuffer(m * 32) for _ in range(ranks)]
+    mg = multi_gpu.MultiGpu([0] * ranks, transport)
+    try:
+        for _ in range(2):  # the second round hits the workers' twiddle caches
+            for r in range(ranks):
+                part = multi_gpu.slab_of(x, ranks, r)  # held while the copy runs
+                ffi.check(ffi.load().panda_memcpy(slabs[r].ptr, C.c_void_p(part.ctypes.data), m * 32), "copy")
+            flags = mg.ntt([b.ptr.value for b in slabs], [b.ptr.value for b in scratches], om, log_n)
+            outs = [(scratches[r] if flags[r] else slabs[r]).to_host().reshape(m, 8) for r in range(ranks)]
+            assert (multi_gpu.natural_from_slab_outputs(outs) == po.ntt(fid, x, om, log_n)).all()
+        if ranks > 1 or log_n >= 2:
+            src = [(scratches[r], slabs[r]) if flags[r] else (slabs[r], scratches[r]) for r in range(ranks)]
+            back = mg.ntt([a.ptr.value for a, _ in src], [b.ptr.value for _, b in src], om, log_n, inverse=True)
+            for r in range(ranks):
+                got = (src[r][1] if back[r] else src[r][0]).to_host().reshape(m, 8)
+                assert (got == multi_gpu.slab_of(x, ranks, r)).all(), r
+    finally:
+        mg.close()
+        for d in slabs + scratches:
+            d.free()
+
+
+def test_c_abi_multi_gpu_bad_arguments(gm):
+    lib = ffi.load()
+    h = ffi.PandaMultiGpu()
+    one = (C.c_int * 1)(0)
+    two = (C.c_int * 2)(0, 0)
+    assert lib.panda_multi_gpu_create(C.byref(h), one, 0, ffi.MULTI_RCCL) == 1
+    assert lib.panda_multi_gpu_create(C.byref(h), two, 2, ffi.MULTI_RCCL) == 1       # RCCL: one rank per device
+    assert lib.panda_multi_gpu_create(C.byref(h), (C.c_int * 1)(99), 1, ffi.MULTI_RCCL) == 1
+    assert lib.panda_multi_gpu_create(C.byref(h), one, 1, 7) == 1
+    mg = multi_gpu.MultiGpu([0, 0, 0], ffi.MULTI_LOOPBACK)                           # three ranks: fine for an MSM, not for the slab NTT
+    try:
+        d = DeviceBuffer(3 << 12)
+        om = po.root_of_unity(po.F_BN254_FR, 9)
+        flag = C.c_uint(0)
+        cfgs = (ffi.NttSlabConfiguration * 3)(*[ffi.NttSlabConfiguration(ffi.PandaStream(), d.ptr, d.ptr, C.c_void_p(om.ctypes.data), 9, 1, r, C.pointer(flag))
+                                                for r in range(3)])
+        assert lib.panda_ntt_execute_bn254_multi(mg.handle, cfgs) == 1
+        assert lib.panda_ntt_execute_bn254_multi(mg.handle, None) == 1
+        assert lib.panda_msm_execute_bn254_multi(mg.handle, None, None) == 1
+        d.free()
+    finally:
+        mg.close()
+
+
 def test_cpp_gpu_manager_mirror():
     """The C++ mirror of the reference's Rust gpu_manager + its integration test binary (panda_amd/csrc/tests/manager_test.cpp,
     the counterpart of tests/test.rs): device MSM vs the CPU entry point, cached variants, NTT round trips."""
