@@ -939,6 +939,46 @@ def test_msm_precomputed_tables_skewed_2_15(gm, kind):
     assert (affine_of(0, out) == po.expected_from_linearity(0, 56, scalars)).all()
 
 
+@pytest.mark.parametrize("kind", ["all_equal", "half_zero", "three_values", "all_equal_from_host_5_ranges"])
+def test_msm_skewed_scalars_full_size_2_22(gm, kind):
+    """Skew at a size where it bites: 2^22 points with precomputed tables.  Equal scalars put 2^22 entries into ONE bucket per window
+    (buckets cut into tens of thousands of chunk pieces: the k_fixup_long queue; level-2 / level-3 sort segments far beyond a tile),
+    half-zero scalars halve every list, three distinct values load three buckets per window.  Checked by linearity over all scalars;
+    the last case goes through panda_msm_execute_from_host with five upload ranges (range buckets merged by the fix-ups)."""
+    lib = ffi.load()
+    k = 22
+    n = 1 << k
+    seed_b = 0x70616E6461 ^ 0x5EED22
+    db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
+    ffi.check(lib.panda_gen_bases(0, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    if kind.startswith("all_equal"):
+        scalars = np.tile(po.gen_scalars(po.F_BN254_FR, 771, 1), (n, 1))
+    elif kind == "half_zero":
+        ffi.check(lib.panda_gen_scalars(0, 772, 0, n, ds.ptr, NULL_STREAM), "gen")
+        scalars = ds.to_host().reshape(n, 8)
+        scalars[::2] = 0
+    else:
+        three = po.gen_scalars(po.F_BN254_FR, 773, 3)
+        scalars = three[np.random.default_rng(774).integers(0, 3, n)]
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint32)
+    ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(scalars.ctypes.data), n * 32), "copy")
+    ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, k, 0, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    try:
+        if kind.endswith("from_host_5_ranges"):
+            ffi.check(lib.panda_memset(ds.ptr, 0, n * 32), "memset")  # the call fills the device buffer itself
+            ffi.check(lib.panda_msm_execute_from_host(0, cfg, C.c_void_p(scalars.ctypes.data), 5, gm.h2d_stream.raw), "msm")
+        else:
+            ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        got = po.to_affine(0, dr.to_host())
+        assert (ds.to_host().reshape(n, 8) == scalars).all()  # scalars untouched (or uploaded intact)
+    finally:
+        lib.panda_msm_unregister_bases(db.ptr)
+        for d in (db, ds, dr):
+            d.free()
+    assert (got == po.expected_from_linearity(0, seed_b, scalars)).all()
+
+
 @pytest.mark.parametrize("tabled", [False, True])
 def test_msm_batched_pipeline_over_cached_bases(gm, tabled):
     """upload of batch k+1 on the h2d stream under the execution of batch k; results in order and equal
