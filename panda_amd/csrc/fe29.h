@@ -479,6 +479,31 @@ PANDA_HD void fe_sub_raw(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
     }
 }
 
+// The same with the per-limb bias at U * 2^29 (U = 2 is fe_sub_raw, U = 3 admits an un-normalised b: limbs <= 2^30 + 16, the sum of two
+// loose values).  a, b limbs <= 2^30 + 16; the result has limbs < 3 * 2^30 + 32 and may only be the x operand of fe_mul_shoup (whose
+// columns have room for exactly that) or the input of a reduction.
+template <class F, int K, int U>
+PANDA_HD constexpr u32 fe_kp_bias(int i)
+{
+    static_assert(U >= 2 && U <= 4, "bias in units of 2^29");
+    return i == 0 ? F::KP[K][0] - ((u32)(4 - U) << LIMB_BITS) : (i < F::N - 1 ? F::KP[K][i] - ((u32)(4 - U) << LIMB_BITS) + (u32)(4 - U) : F::KP[K][i] + (u32)(4 - U));
+}
+template <class F, int KB, int U>
+PANDA_HD void fe_sub_raw_bias(Fe<F> &r, const Fe<F> &a, const Fe<F> &b)
+{
+    static_assert(RawOperandOk<F>::value, "no column headroom for a raw operand in this field");
+    constexpr int K = KB + SubMargin<F>::value;
+    static_assert(K <= 200, "subtraction constant table too small");
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+        const u32 kp = fe_kp_bias<F, K, U>(i);
+#if defined(FE29_CHECK)
+        assert((u64)a.l[i] + kp >= b.l[i] && (u64)a.l[i] + kp - b.l[i] < 3 * (1ull << 30) + 64 && "fe_sub_raw_bias limb range");
+#endif
+        r.l[i] = a.l[i] + kp - b.l[i];
+    }
+}
+
 // r = KEFF*p - a, a < KB*p, without the carry pass (see fe_sub_raw)
 template <class F, int KB>
 PANDA_HD void fe_neg_raw(Fe<F> &r, const Fe<F> &a)
@@ -620,7 +645,8 @@ PANDA_HD void fe_reduce_small(Fe<F> &a)
 // for N = 9.  No radix factor appears: x w mod p is in whatever form x was (the NTT multiplies wire-form residues by
 // plain-integer twiddles and gets wire-form residues back).
 //
-//   fe_mul_shoup   needs  limb(x) < 2^31 + 2^24 (tight, loose or the output of fe_sub_raw), value(x) < R for the bound given
+//   fe_mul_shoup   needs  limb(x) < 3 * 2^30 + 64 (tight, loose, or the output of fe_sub_raw / fe_sub_raw_bias: nine such limbs times a
+//                         29-bit limb of the constant, plus the nine q * (R - p) terms of the low half, stay below 2^64), value(x) < R for the bound given
 //                  gives  tight, value < 3p  (exactly: < (x / R + 2) p)
 template <class F>
 struct FeTw {
@@ -703,7 +729,7 @@ PANDA_HD void fe_mul_shoup(Fe<F> &r, const Fe<F> &x, const u32 *w, const u32 *wq
 #pragma unroll
             for (int i = (c < N ? 0 : c - N + 1); i <= (c < N ? c : N - 1); i++) {
 #if defined(FE29_CHECK)
-                assert(x.l[i] < (1u << 31) + (1u << 24) && wq[c - i] < (1u << 29) && "fe_mul_shoup operand range");
+                assert(x.l[i] < 3 * (1ull << 30) + 64 && wq[c - i] < (1u << 29) && "fe_mul_shoup operand range");
 #endif
                 FE29_MAC(acc, x.l[i], wq[c - i]);
                 FE29_SHADOW_MAC(x.l[i], wq[c - i])

@@ -123,42 +123,36 @@ struct Plan8 {
 template <class Fr, int B0>
 inline constexpr Plan8<Fr, B0> plan8_v{};
 
-// one radix-2 butterfly on registers: a <- a + b, b <- (a - b + K p) [* w].  RAW: leave both outputs un-normalised (limbs < 2^31;
-// the last round, whose outputs go straight into a product or a reduction)
-template <class Fr, int B, bool MULT, bool RED, bool UNIFORM, bool RAW = false>
+// One radix-2 butterfly on registers: a <- a + b, b <- (a - b + K p) [* w].  Carry passes are spent where the limbs need them, not
+// after every addition (MODE by round parity):
+//   MODE 0 (rounds 0, 2, 4, 6)  inputs tight or loose; the sum is left un-normalised (limbs <= 2^30 + 16)
+//   MODE 1 (rounds 1, 3, 5)     inputs may be such sums; the difference takes the 3 * 2^29 bias that covers them and goes into the
+//                               product as it is (limbs < 3 * 2^30 + 32, what fe_mul_shoup's columns hold); the sum is normalised
+//   MODE 2 (round 7)            inputs as MODE 1; both outputs stay un-normalised: they go straight into the output product or reduction
+template <class Fr, int B, bool MULT, bool RED, bool UNIFORM, int MODE>
 __device__ __forceinline__ void bfly(Fe<Fr> &a, Fe<Fr> &b, const u32 *w, const u32 *wq)
 {
     static_assert(B + SubMargin<Fr>::value <= 200, "subtraction constant table too small");
-    Fe<Fr> s;
+    static_assert(!(MODE == 2 && (MULT || RED)), "the last round only adds and subtracts");
+    Fe<Fr> s, d;
+    fe_add_nr(s, a, b);
     if constexpr (MULT) {
         static_assert(round_ok<Fr>(B), "operand of the twiddle product must stay below R");
         Fe<Fr> x;
-        fe_sub_raw<Fr, B>(x, a, b);
-        if constexpr (RED) {
-            fe_add_nr(s, a, b);
-            fe_reduce_mad_2p(s);
-        } else
-            fe_add(s, a, b);
-        fe_mul_shoup<Fr, UNIFORM>(b, x, w, wq);
-        a = s;
-    } else if constexpr (RAW) {
-        Fe<Fr> d;
-        fe_sub_raw<Fr, B>(d, a, b);
-        fe_add_nr(s, a, b);
-        a = s;
-        b = d;
-    } else {
-        Fe<Fr> d;
-        fe_sub<Fr, B>(d, a, b);
-        if constexpr (RED) {
-            fe_add_nr(s, a, b);
-            fe_reduce_mad_2p(s);
-            fe_reduce_mad_2p(d);
-        } else
-            fe_add(s, a, b);
-        a = s;
-        b = d;
+        fe_sub_raw_bias<Fr, B, MODE == 0 ? 2 : 3>(x, a, b);
+        fe_mul_shoup<Fr, UNIFORM>(d, x, w, wq);
+    } else if constexpr (MODE == 2)
+        fe_sub_raw_bias<Fr, B, 3>(d, a, b);
+    else {
+        fe_sub<Fr, B>(d, a, b); // limbs of b < 2^31 - 4: fine for either input class
+        if constexpr (RED) fe_reduce_mad_2p(d);
     }
+    if constexpr (RED)
+        fe_reduce_mad_2p(s);
+    else if constexpr (MODE == 1)
+        fe_norm(s, s);
+    a = s;
+    b = d;
 }
 
 __device__ __forceinline__ unsigned brev(unsigned v, unsigned bits) { return __brev(v) >> (32 - bits); } // bits >= 1
@@ -261,19 +255,19 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             load_tw2(t, s_tw, i0 + 32 * m);
-            bfly<Fr, PL.b[0], true, PL.red[0], false>(e[m], e[m + 4], t.w, t.q);
+            bfly<Fr, PL.b[0], true, PL.red[0], false, 0>(e[m], e[m + 4], t.w, t.q);
         }
         // round 1: pairs (m, m + 2), twiddle index 2 (i0 + 32 (m & 1))
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             load_tw2(t, s_tw, 2 * (i0 + 32 * h));
-            bfly<Fr, PL.b[1], true, PL.red[1], false>(e[h], e[h + 2], t.w, t.q);
-            bfly<Fr, PL.b[1], true, PL.red[1], false>(e[h + 4], e[h + 6], t.w, t.q);
+            bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h], e[h + 2], t.w, t.q);
+            bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h + 4], e[h + 6], t.w, t.q);
         }
         // round 2: pairs (m, m + 1), twiddle index 4 i0
         load_tw2(t, s_tw, 4 * i0);
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[2], true, PL.red[2], false>(e[m], e[m + 1], t.w, t.q);
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[2], true, PL.red[2], false, 0>(e[m], e[m + 1], t.w, t.q);
     }
 
     // ---- exchange 1: element (s, i) lives at word s | ((i[7:5] ^ i[1:0]) << 3) | (i[4:0] << 6) of each plane
@@ -294,34 +288,34 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
         const unsigned j0 = wave;
         TwV<Fr> t;
         if (j0 == 0) { // twiddle 1 wherever the register bits below the round's own are clear
-            bfly<Fr, PL.b[3], false, PL.red[3], true>(e[0], e[4], nullptr, nullptr);
+            bfly<Fr, PL.b[3], false, PL.red[3], true, 1>(e[0], e[4], nullptr, nullptr);
 #pragma unroll
             for (int m = 1; m < 4; m++) {
                 load_tw2_uniform(t, A.pq, 32 * m);
-                bfly<Fr, PL.b[3], true, PL.red[3], true>(e[m], e[m + 4], t.w, t.q);
+                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q);
             }
-            bfly<Fr, PL.b[4], false, PL.red[4], true>(e[0], e[2], nullptr, nullptr);
-            bfly<Fr, PL.b[4], false, PL.red[4], true>(e[4], e[6], nullptr, nullptr);
+            bfly<Fr, PL.b[4], false, PL.red[4], true, 0>(e[0], e[2], nullptr, nullptr);
+            bfly<Fr, PL.b[4], false, PL.red[4], true, 0>(e[4], e[6], nullptr, nullptr);
             load_tw2_uniform(t, A.pq, 64);
-            bfly<Fr, PL.b[4], true, PL.red[4], true>(e[1], e[3], t.w, t.q);
-            bfly<Fr, PL.b[4], true, PL.red[4], true>(e[5], e[7], t.w, t.q);
+            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[1], e[3], t.w, t.q);
+            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[5], e[7], t.w, t.q);
 #pragma unroll
-            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], false, PL.red[5], true>(e[m], e[m + 1], nullptr, nullptr);
+            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], false, PL.red[5], true, 1>(e[m], e[m + 1], nullptr, nullptr);
         } else {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
-                bfly<Fr, PL.b[3], true, PL.red[3], true>(e[m], e[m + 4], t.w, t.q);
+                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q);
             }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 load_tw2_uniform(t, A.pq, 16 * (4 * h + j0));
-                bfly<Fr, PL.b[4], true, PL.red[4], true>(e[h], e[h + 2], t.w, t.q);
-                bfly<Fr, PL.b[4], true, PL.red[4], true>(e[h + 4], e[h + 6], t.w, t.q);
+                bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h], e[h + 2], t.w, t.q);
+                bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h + 4], e[h + 6], t.w, t.q);
             }
             load_tw2_uniform(t, A.pq, 32 * j0);
 #pragma unroll
-            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true>(e[m], e[m + 1], t.w, t.q);
+            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true, 1>(e[m], e[m + 1], t.w, t.q);
         }
     }
 
@@ -353,12 +347,12 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     {
         TwV<Fr> t;
         load_tw2_uniform(t, A.pq, 64);
-        bfly<Fr, PL.b[6], false, PL.red[6], true>(e[0], e[2], nullptr, nullptr);
-        bfly<Fr, PL.b[6], false, PL.red[6], true>(e[4], e[6], nullptr, nullptr);
-        bfly<Fr, PL.b[6], true, PL.red[6], true>(e[1], e[3], t.w, t.q);
-        bfly<Fr, PL.b[6], true, PL.red[6], true>(e[5], e[7], t.w, t.q);
+        bfly<Fr, PL.b[6], false, PL.red[6], true, 0>(e[0], e[2], nullptr, nullptr);
+        bfly<Fr, PL.b[6], false, PL.red[6], true, 0>(e[4], e[6], nullptr, nullptr);
+        bfly<Fr, PL.b[6], true, PL.red[6], true, 0>(e[1], e[3], t.w, t.q);
+        bfly<Fr, PL.b[6], true, PL.red[6], true, 0>(e[5], e[7], t.w, t.q);
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[7], false, PL.red[7], true, !PL.red[7]>(e[m], e[m + 1], nullptr, nullptr);
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[7], false, PL.red[7], true, PL.red[7] ? 1 : 2>(e[m], e[m + 1], nullptr, nullptr);
     }
     constexpr int FB = PL.b[8];
     static_assert(FB < (int)Fr::HEADROOM && FB < 512, "final bound");

@@ -105,6 +105,26 @@ static void shoup(u32 *r, u32 *tw_out, const u32 *x, const u32 *w_internal, size
         }
     }
 }
+// the NTT butterfly's difference path: (a - b + K p) with the U * 2^29 bias, un-normalised, straight into the product
+template <class F, int U>
+static void bfly_diff(u32 *r, const u32 *a, const u32 *b, const u32 *w_internal, size_t n)
+{
+    constexpr int N = F::N;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> ae, be, we, x, re;
+        for (int j = 0; j < N; j++) {
+            ae.l[j] = a[i * N + j];
+            be.l[j] = b[i * N + j];
+            we.l[j] = w_internal[i * N + j];
+        }
+        FeTw<F> t;
+        fe_shoup_prepare(t, we);
+        fe_sub_raw_bias<F, 8, U>(x, ae, be);
+        fe_mul_shoup(re, x, t);
+        for (int j = 0; j < N; j++) r[i * N + j] = re.l[j];
+    }
+}
+
 template <class F>
 static void reduce_mad(u32 *r, const u32 *x, size_t n)
 {
@@ -124,6 +144,16 @@ int h29_shoup(int field_id, u32 *r, u32 *tw_out, const u32 *x, const u32 *w_inte
     case 1: shoup<Bn254Fr>(r, tw_out, x, w_internal, n); return 0;
     case 3: shoup<Bls377Fr>(r, tw_out, x, w_internal, n); return 0;
     case 5: shoup<Bls381Fr>(r, tw_out, x, w_internal, n); return 0;
+    }
+    return 1;
+}
+int h29_bfly_diff(int field_id, int bias_units, u32 *r, const u32 *a, const u32 *b, const u32 *w_internal, size_t n)
+{
+    if (bias_units != 2 && bias_units != 3) return 1;
+    switch (field_id) {
+    case 1: bias_units == 2 ? bfly_diff<Bn254Fr, 2>(r, a, b, w_internal, n) : bfly_diff<Bn254Fr, 3>(r, a, b, w_internal, n); return 0;
+    case 3: bias_units == 2 ? bfly_diff<Bls377Fr, 2>(r, a, b, w_internal, n) : bfly_diff<Bls377Fr, 3>(r, a, b, w_internal, n); return 0;
+    case 5: bias_units == 2 ? bfly_diff<Bls381Fr, 2>(r, a, b, w_internal, n) : bfly_diff<Bls381Fr, 3>(r, a, b, w_internal, n); return 0;
     }
     return 1;
 }

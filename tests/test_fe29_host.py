@@ -203,3 +203,49 @@ def test_multiply_add_reduction(h29, fid):
         got = sum(int(r[i, j]) << (W * j) for j in range(N))
         assert all(int(r[i, j]) < (1 << W) for j in range(N))
         assert got % mod == vals[i] % mod and got < 2 * mod
+
+
+@pytest.mark.parametrize("fid,units", [(1, 2), (1, 3), (3, 3), (5, 3)])
+def test_butterfly_difference_into_product(h29, fid, units):
+    """The NTT butterfly's difference: a - b + K p with the per-limb bias at `units` * 2^29 and NO carry pass, fed straight into the
+    precomputed-quotient product.  Operands at the edge of their limb class -- loose (2^29 + 8) for 2 units, un-normalised sums
+    (2^30 + 16) for 3 -- and values up to 8 p; the library's own asserts (limb ranges, 128-bit shadow columns) run inside."""
+    info = po.field_info(fid)
+    mod = pyref.limbs_to_int(info["p"])
+    N, W = 9, 29
+    R = 1 << (W * N)
+    rng = np.random.default_rng(970 + fid + units)
+    n = 3000
+    lim = (1 << 29) + 8 if units == 2 else (1 << 30) + 16
+
+    def operands():
+        v = np.empty((n, N), dtype=np.uint32)
+        vals = []
+        for i in range(n):
+            k = int(rng.integers(0, 8))
+            val = k * mod + int.from_bytes(rng.bytes(40), "little") % mod
+            l = [(val >> (W * j)) & ((1 << W) - 1) for j in range(N - 1)] + [val >> (W * (N - 1))]
+            for j in range(N - 1, 0, -1):  # push weight downwards until the limbs sit at the top of their class
+                t = min((lim - l[j - 1]) >> W, l[j]) if i % 3 else 0
+                l[j] -= t
+                l[j - 1] += t << W
+            assert all(0 <= a <= lim for a in l[:-1]) and sum(a << (W * j) for j, a in enumerate(l)) == val
+            v[i] = l
+            vals.append(val)
+        return v, vals
+
+    a, av = operands()
+    b, bv = operands()
+    a[:20, :N - 1] = lim  # every column at its maximum (the value no longer matters for the limb asserts; keep it below the bound)
+    b[:20, :N - 1] = 0
+    av[:20] = [sum(int(x) << (W * j) for j, x in enumerate(row)) for row in a[:20]]
+    bv[:20] = [sum(int(x) << (W * j) for j, x in enumerate(row)) for row in b[:20]]
+    ws = [int.from_bytes(rng.bytes(40), "little") % mod for _ in range(n)]
+    w_int = np.array([[((w * R % mod) >> (W * j)) & ((1 << W) - 1) if j < N - 1 else (w * R % mod) >> (W * (N - 1)) for j in range(N)] for w in ws], dtype=np.uint32)
+    r = np.empty((n, N), dtype=np.uint32)
+    assert h29.h29_bfly_diff(fid, units, _p(r), _p(a), _p(b), _p(w_int), C.c_size_t(n)) == 0
+    for i in range(n):
+        got = sum(int(r[i, j]) << (W * j) for j in range(N))
+        assert all(int(r[i, j]) < (1 << W) for j in range(N))
+        assert got % mod == (av[i] - bv[i]) * ws[i] % mod
+        assert got < 4 * mod
