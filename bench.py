@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--log-n", type=int, default=24, help="log2 of the points per GPU of the headline leg (contract: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-ntt-sweep", action="store_true", help="NTT leg: 2^24 only (profiling runs: one size per kernel in the counters)")
     ap.add_argument("--no-config4", action="store_true", help="skip the 2^26-total strong-scaling leg")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config 2 / config 5 legs (N = 1)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
@@ -473,7 +474,7 @@ def main():
         leg("config4_msm_2_26", lambda: config4(ctx, args.config4_total_log_n))
     if not args.no_ntt:
         if world == 1:
-            leg("ntt", lambda: ntt_figure(ctx))
+            leg("ntt", lambda: ntt_figure(ctx, sweep=not args.no_ntt_sweep))
         elif world & (world - 1) == 0:
             leg("ntt_sharded", lambda: ntt_sharded_figure(ctx))
     if world == 1 and not args.no_extra_configs:
@@ -667,13 +668,14 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 
 
-def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7) -> dict:
+def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7, sweep: bool = True) -> dict:
     """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26."""
     res = ntt_one(ctx, log_n, reps)
     res["metric"] = "NTT elements/s (BN254 Fr, 2^24, forward)"
     res["timing"] = ("ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); "
                      "wall_ms = host time of the synchronous call")
-    res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 5) for k in (20, 22, 26)}
+    if sweep:
+        res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 5) for k in (20, 22, 26)}
     return res
 
 

@@ -130,7 +130,7 @@ inline constexpr Plan8<Fr, B0> plan8_v{};
 //                               product as it is (limbs < 3 * 2^30 + 32, what fe_mul_shoup's columns hold); the sum is normalised
 //   MODE 2 (round 7)            inputs as MODE 1; both outputs stay un-normalised: they go straight into the output product or reduction
 template <class Fr, int B, bool MULT, bool RED, bool UNIFORM, int MODE>
-__device__ __forceinline__ void bfly(Fe<Fr> &a, Fe<Fr> &b, const u32 *w, const u32 *wq)
+__device__ __forceinline__ void bfly(Fe<Fr> &a, Fe<Fr> &b, const u32 *w, const u32 *wq, bool unit = false)
 {
     static_assert(B + SubMargin<Fr>::value <= 200, "subtraction constant table too small");
     static_assert(!(MODE == 2 && (MULT || RED)), "the last round only adds and subtracts");
@@ -140,7 +140,11 @@ __device__ __forceinline__ void bfly(Fe<Fr> &a, Fe<Fr> &b, const u32 *w, const u
         static_assert(round_ok<Fr>(B), "operand of the twiddle product must stay below R");
         Fe<Fr> x;
         fe_sub_raw_bias<Fr, B, MODE == 0 ? 2 : 3>(x, a, b);
-        fe_mul_shoup<Fr, UNIFORM>(d, x, w, wq);
+        if (unit) { // wave-uniform: this wave's twiddle is 1 -- the difference only needs its carries
+            fe_norm(d, x);
+            if constexpr (RED) fe_reduce_mad_2p(d);
+        } else
+            fe_mul_shoup<Fr, UNIFORM>(d, x, w, wq);
     } else if constexpr (MODE == 2)
         fe_sub_raw_bias<Fr, B, 3>(d, a, b);
     else {
@@ -284,39 +288,27 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     }
 
     // ---- block B: rounds 3..5 (distances 16, 8, 4).  Twiddle indices 8 (4 (m & 3) + j0), 16 (4 (m & 1) + j0), 32 j0: wave-uniform
+    // In wave 0 the twiddle is 1 wherever the register bits below the round's own are clear (7 of its 12 butterflies): those skip the
+    // product.  One code path with a wave-uniform test per butterfly -- as two separate paths the compiler hoisted their common sums
+    // and differences above the branch and spilled 68 registers there.
     {
         const unsigned j0 = wave;
+        const bool w0 = j0 == 0;
         TwV<Fr> t;
-        if (j0 == 0) { // twiddle 1 wherever the register bits below the round's own are clear
-            bfly<Fr, PL.b[3], false, PL.red[3], true, 1>(e[0], e[4], nullptr, nullptr);
 #pragma unroll
-            for (int m = 1; m < 4; m++) {
-                load_tw2_uniform(t, A.pq, 32 * m);
-                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q);
-            }
-            bfly<Fr, PL.b[4], false, PL.red[4], true, 0>(e[0], e[2], nullptr, nullptr);
-            bfly<Fr, PL.b[4], false, PL.red[4], true, 0>(e[4], e[6], nullptr, nullptr);
-            load_tw2_uniform(t, A.pq, 64);
-            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[1], e[3], t.w, t.q);
-            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[5], e[7], t.w, t.q);
-#pragma unroll
-            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], false, PL.red[5], true, 1>(e[m], e[m + 1], nullptr, nullptr);
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
-                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                load_tw2_uniform(t, A.pq, 16 * (4 * h + j0));
-                bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h], e[h + 2], t.w, t.q);
-                bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h + 4], e[h + 6], t.w, t.q);
-            }
-            load_tw2_uniform(t, A.pq, 32 * j0);
-#pragma unroll
-            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true, 1>(e[m], e[m + 1], t.w, t.q);
+        for (int m = 0; m < 4; m++) {
+            load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
+            bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q, m == 0 && w0);
         }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            load_tw2_uniform(t, A.pq, 16 * (4 * h + j0));
+            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h], e[h + 2], t.w, t.q, h == 0 && w0);
+            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h + 4], e[h + 6], t.w, t.q, h == 0 && w0);
+        }
+        load_tw2_uniform(t, A.pq, 32 * j0);
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true, 1>(e[m], e[m + 1], t.w, t.q, w0);
     }
 
     // ---- exchange 2: element (s, i) lives at word b | (s << 5) | (i[2:0] << 8), b[1:0] = i[6:5] ^ i[4:3], b[4:2] = s ^ (i[7], i[4:3])
@@ -377,28 +369,36 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     } else {
         const size_t base = ((size_t)(blk - k) << 8) + k + ((size_t)iq << lgp);
         const unsigned i2 = (blk >> lgp) >> A.i2_shift;
+        // The table entries of the eight products are fetched one product ahead and no further (a scheduling barrier per element):
+        // hoisted all at once they are 160 registers, and the spills that buys showed up as 0.8 GB of scratch traffic per launch
         if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
             const unsigned row = i2 << A.ca;
+            TwV<Fr> nxt;
+            load_tw2(nxt, A.ta, row | iq);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                TwV<Fr> t;
-                load_tw2(t, A.ta, row | ((br3(m) << 5) | iq));
+                const TwV<Fr> t = nxt;
+                if (m + 1 < 8) load_tw2(nxt, A.ta, row | ((br3(m + 1) << 5) | iq));
                 Fe<Fr> v;
                 fe_mul_shoup<Fr, false>(v, e[m], t.w, t.q);
                 store_elem32(A.y + (base + ((size_t)(br3(m) << 5) << lgp)) * 8, v);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else { // k2 = i_out 2^lgp + k: the low ca (<= lgp) bits are the thread's, the rest the element's
             TwV<Fr> ta;
             load_tw2(ta, A.ta, (i2 << A.ca) | (k & ((1u << A.ca) - 1)));
             const unsigned rowb = i2 << A.cb, khi0 = k >> A.ca, sh = lgp - A.ca;
+            TwV<Fr> nxt;
+            load_tw2(nxt, A.tb, rowb | ((iq << sh) | khi0));
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                TwV<Fr> t;
-                load_tw2(t, A.tb, rowb | ((((br3(m) << 5) | iq) << sh) | khi0));
+                const TwV<Fr> t = nxt;
+                if (m + 1 < 8) load_tw2(nxt, A.tb, rowb | ((((br3(m + 1) << 5) | iq) << sh) | khi0));
                 Fe<Fr> v, u;
                 fe_mul_shoup<Fr, false>(u, e[m], t.w, t.q);
                 fe_mul_shoup<Fr, false>(v, u, ta.w, ta.q);
                 store_elem32(A.y + (base + ((size_t)(br3(m) << 5) << lgp)) * 8, v);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

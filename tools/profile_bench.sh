@@ -7,8 +7,8 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq
-PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-config4 --no-extra-configs"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-compare --no-config4 --no-extra-configs > gpurun_out/prof_stats.log 2>&1
+PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-config4 --no-extra-configs --no-ntt-sweep"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-compare --no-config4 --no-extra-configs --no-ntt-sweep > gpurun_out/prof_stats.log 2>&1
 echo "stats pass done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o bench --output-format csv -- python3 bench.py $PMC_ARGS > gpurun_out/prof_fetch.log 2>&1
 echo "fetch pass done"

@@ -22,7 +22,12 @@ def latest(pattern):
 def short(k):
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"([A-Za-z_0-9:]+)", k)
-    return m.group(1) if m else k[:30]
+    name = m.group(1) if m else k[:30]
+    name = name.split("::")[-1]
+    p8 = re.search(r"k_ntt_pass8<[^,]+, (true|false), (true|false)", k)
+    if p8:  # the three roles of the register-resident radix-256 pass are three kernels
+        name += "_first" if p8.group(1) == "true" else ("_last" if p8.group(2) == "true" else "_middle")
+    return name
 
 
 def main():
