@@ -629,7 +629,7 @@ def pcie_inclusive(ctx: Ctx, prob: MsmProblem) -> dict:
 
 
 def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
-    """forward and inverse BN254 NTT of 2^log_n device-resident elements, median of `reps`"""
+    """forward and inverse BN254 NTT of 2^log_n device-resident elements: 3 warm-up calls, median of `reps`"""
     torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
     n = 1 << log_n
     a = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
@@ -644,12 +644,12 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
         t_exec, first kernel to result ready --, host wall time of the synchronous call)"""
         dev_ts, wall_ts = [], []
         ms = C.c_float(0)
-        for r in range(reps + 1):
+        for r in range(reps + 3):  # SURVEY 8d: 3 warm-ups, median of >= 10
             t = time.perf_counter()
             ffi.check(fn(cfg), "ntt")
             w = time.perf_counter() - t
             ffi.check(lib.panda_ntt_last_device_ms(C.byref(ms)), "ntt_ms")
-            if r:
+            if r >= 3:
                 wall_ts.append(w)
                 dev_ts.append(ms.value * 1e-3)
         dev_ts.sort()
@@ -668,14 +668,14 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 
 
-def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 7, sweep: bool = True) -> dict:
+def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True) -> dict:
     """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26."""
     res = ntt_one(ctx, log_n, reps)
     res["metric"] = "NTT elements/s (BN254 Fr, 2^24, forward)"
     res["timing"] = ("ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); "
                      "wall_ms = host time of the synchronous call")
     if sweep:
-        res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 5) for k in (20, 22, 26)}
+        res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 11) for k in (20, 22, 26)}
     return res
 
 
