@@ -448,6 +448,21 @@ void launch_pass8(bool first, bool last, const panda_ntt8::Pass8Args &a, unsigne
         hipLaunchKernelGGL((k_ntt_pass8<Fr, false, false, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
 }
 
+// short last pass / size-G slab transforms in registers (radix 2, 4, 8): d_pq holds max(1, 2^(deg-1)) precomputed-quotient entries
+template <class Fr>
+void launch_small(unsigned deg, const u32 *x, u32 *y, const u32 *d_pq, unsigned log_count, bool br_out, hipStream_t s)
+{
+    using namespace panda_ntt8;
+    const SmallArgs a{x, y, d_pq, log_count, br_out ? 1u : 0u};
+    const unsigned blocks = (unsigned)((((u64)1 << log_count) + 255) / 256);
+    if (deg == 1)
+        hipLaunchKernelGGL((k_ntt_small<Fr, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (deg == 2)
+        hipLaunchKernelGGL((k_ntt_small<Fr, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_ntt_small<Fr, 3>), dim3(blocks), dim3(256), 0, s, a);
+}
+
 template <class Fr>
 void launch_pass(unsigned deg, const PassArgs &a, unsigned tiles, hipStream_t s)
 {
@@ -696,6 +711,13 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
                 }
             }
             launch_pass8<Fr>(passes == 0, last, a, (unsigned)(n / panda_ntt8::ELEMS), stream);
+        } else if (regs8 && last && deg <= 3) {
+            // a short last pass behind k_ntt_pass8 (its twiddle is already on the data): radix 2 / 4 / 8 in registers
+            if (build) {
+                fe_pow_u64(base, omega, n >> deg);
+                build_table2<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
+            }
+            launch_small<Fr>(deg, src, dst, d_pq, log_n - deg, br_out, stream);
         } else {
             PassArgs a{};
             a.x = src;
@@ -947,7 +969,16 @@ hipError_t slab_step2(const panda_ntt_slab_configuration &cfg, bool wait, bool i
             omega = oi;
         }
         fe_pow_u64(base, omega, m); // w^m (w^-m for the inverse) has order G
-        build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
+        if (cfg.log_ranks <= 3)
+            build_table2<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
+        else
+            build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << cfg.log_ranks) >> 1), d_pq);
+    }
+    if (cfg.log_ranks <= 3) { // 2, 4 or 8 ranks: the size-G transforms run in registers, one thread per column of the G x m/G slab
+        launch_small<Fr>(cfg.log_ranks, (const u32 *)cfg.d_slab, (u32 *)cfg.d_scratch, d_pq, log_m - cfg.log_ranks, false, stream);
+        PANDA_TRY(hipGetLastError());
+        if (cfg.flag) *(unsigned *)cfg.flag = 1;
+        return slab_finish(tw, key, stream, wait);
     }
     PassArgs a{};
     a.x = (const u32 *)cfg.d_slab;

@@ -404,4 +404,66 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     }
 }
 
+// ---- a short LAST pass (radix 2, 4 or 8) entirely in registers ------------------------------------------------------------------------
+// The last pass of a transform whose size is not a multiple of 8 bits (2^26 = 8 + 8 + 8 + 2), and the size-G transforms of the sharded
+// transform's second step (G = 2, 4, 8 ranks): thread blk owns the 2^DEG elements x[blk + i S] of one sub-transform, runs its DEG
+// rounds in registers (twiddles are powers of a 2^DEG-th root: scalar registers, 0 / 1 / 5 products per sub-transform), reduces to
+// [0, p) and writes y[blk + i_out S] -- or, bit-reversed, the 2^DEG contiguous elements at bitrev(blk) 2^DEG.  No LDS, no
+// barrier: a streaming kernel, 64 B of traffic per element.  Inputs below 3p; the twiddle between the passes was multiplied on by the
+// pass before (k_ntt_pass8) or is not needed (second slab step).
+struct SmallArgs {
+    const u32 *x;
+    u32 *y;
+    const u32 *pq;      // max(1, 2^(DEG-1)) entries: powers of the 2^DEG-th root
+    unsigned log_count; // log2 of the number of sub-transforms (= of the stride S)
+    unsigned br_out;
+};
+
+template <class Fr, int DEG>
+__global__ void __launch_bounds__(256) k_ntt_small(SmallArgs A)
+{
+    static_assert(DEG >= 1 && DEG <= 3, "radix 2, 4 or 8");
+    constexpr int R = 1 << DEG;
+    const size_t S = (size_t)1 << A.log_count;
+    const size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= S) return;
+    Fe<Fr> e[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) load_elem32(e[i], A.x + (blk + i * S) * 8);
+    // bounds 3 -> 7 -> 15 -> 31 (each round at most doubles and adds one): far below R / p for every supported field
+    TwV<Fr> t;
+    if constexpr (DEG == 1) {
+        bfly<Fr, 3, false, false, true, 2>(e[0], e[1], nullptr, nullptr);
+    } else if constexpr (DEG == 2) {
+        load_tw2_uniform(t, A.pq, 1);
+        bfly<Fr, 3, false, false, true, 0>(e[0], e[2], nullptr, nullptr);
+        bfly<Fr, 3, true, false, true, 0>(e[1], e[3], t.w, t.q);
+        bfly<Fr, 7, false, false, true, 2>(e[0], e[1], nullptr, nullptr);
+        bfly<Fr, 7, false, false, true, 2>(e[2], e[3], nullptr, nullptr);
+    } else {
+        bfly<Fr, 3, false, false, true, 0>(e[0], e[4], nullptr, nullptr);
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            load_tw2_uniform(t, A.pq, i);
+            bfly<Fr, 3, true, false, true, 0>(e[i], e[i + 4], t.w, t.q);
+        }
+        load_tw2_uniform(t, A.pq, 2);
+        bfly<Fr, 7, false, false, true, 1>(e[0], e[2], nullptr, nullptr);
+        bfly<Fr, 7, false, false, true, 1>(e[4], e[6], nullptr, nullptr);
+        bfly<Fr, 7, true, false, true, 1>(e[1], e[3], t.w, t.q);
+        bfly<Fr, 7, true, false, true, 1>(e[5], e[7], t.w, t.q);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) bfly<Fr, 15, false, false, true, 2>(e[i], e[i + 1], nullptr, nullptr);
+    }
+    // position i holds output bitrev(i)
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        fe_reduce_mad_2p(e[i]);
+        fe_reduce_once(e[i]);
+        const unsigned i_out = (unsigned)(DEG == 1 ? i : (DEG == 2 ? (((i & 1) << 1) | (i >> 1)) : br3(i)));
+        const size_t dst = A.br_out ? ((size_t)brev0((unsigned)blk, A.log_count) << DEG) + i : blk + i_out * S;
+        store_elem32(A.y + dst * 8, e[i]);
+    }
+}
+
 } // namespace panda_ntt8
