@@ -674,8 +674,9 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
         u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB), *d_pq = (u32 *)arena.take(SZ_PQ);
         if (!d_ta || !d_tb || !d_pq) return hipErrorOutOfMemory;
         Fe<Fr> base;
-        if (regs8 && deg == 8) {
+        if (regs8 && (deg == 8 || (last && deg >= 4))) { // a last pass of radix 16 ... 128 runs as k_ntt_pass8 with its first 8 - deg rounds off
             panda_ntt8::Pass8Args a{};
+            a.skip = 8 - deg;
             a.x = src;
             a.y = dst;
             a.pq = d_pq;
@@ -685,7 +686,7 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             a.lgp = log_p;
             a.br_in = (br_in && passes == 0) ? 1 : 0;
             a.br_out = (br_out && last) ? 1 : 0;
-            const unsigned deg2 = last ? 0 : std::min(8u, log_n - log_p - 8); // radix of the next pass
+            const unsigned deg2 = last ? 0 : std::min(8u, log_n - log_p - 8); // radix of the next pass (deg == 8 unless last)
             if (!last) {
                 // twiddle W^(i2 k2), W = w^(n / 2^(log_p + 8 + deg2)), k2 < 2^(log_p + 8), i2 < 2^deg2; tables of at most 2^16 entries
                 if (log_p + 8 + deg2 <= 16) {

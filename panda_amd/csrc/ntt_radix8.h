@@ -47,6 +47,10 @@ struct Pass8Args {
                        // tb[(i2 << cb) | (k2 >> ca)]
     unsigned br_in;    // first pass: the caller's input is in bit-reversed order
     unsigned br_out;   // last pass: leave the output in bit-reversed order
+    unsigned skip;     // LAST pass only: a pass of radix 2^(8 - skip), skip = 1 .. 4.  The top `skip` bits of the 8-bit local index then
+                       // select the sub-transform instead of a position in it (a tile holds 8 << skip sub-transforms) and rounds
+                       // 0 .. skip - 1 do not run; the twiddle indices of the remaining rounds are what they were (powers of the
+                       // 256-th root w^(n/256) that are multiples of 2^skip are the powers of the 2^(8-skip)-th root).
 };
 
 template <class Fr>
@@ -216,8 +220,9 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned blk0 = blockIdx.x * SUBS;
-    const unsigned S = (1u << A.log_n) >> 8; // stride between the inputs of one sub-transform
+    const unsigned skip = LAST ? A.skip : 0u, deg = 8 - skip;
+    const unsigned blk0 = blockIdx.x * (SUBS << skip);
+    const unsigned S = (1u << A.log_n) >> deg; // stride between the inputs of one sub-transform
     const unsigned lgp = A.lgp;
 
     // butterfly twiddles of block A -> LDS (2560 words, ten per thread)
@@ -242,13 +247,22 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
             base = ((size_t)brev0(blk0 + s, A.log_n - 8) << 8) + (bi << 3);
 #pragma unroll
             for (int m = 0; m < 8; m++) load_elem32(e[m], A.x + (base + br3(m)) * 8);
-        } else {
+        } else if (skip == 0) {
             s = lane & 7;
             i0 = (lane >> 3) | (wave << 3);
             base = (size_t)(blk0 + s) + (size_t)i0 * S;
             step = (size_t)32 * S;
 #pragma unroll
             for (int m = 0; m < 8; m++) load_elem32(e[m], A.x + (base + m * step) * 8);
+        } else { // local index i8 = i0 + 32 m: its top `skip` bits pick the sub-transform (8 apart), the rest the position
+            s = lane & 7;
+            i0 = (lane >> 3) | (wave << 3);
+            const unsigned mask = (1u << deg) - 1;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const unsigned i8 = i0 + 32 * m;
+                load_elem32(e[m], A.x + ((size_t)(blk0 + ((i8 >> deg) << 3) + s) + (size_t)(i8 & mask) * S) * 8);
+            }
         }
     }
     __syncthreads(); // s_tw complete
@@ -256,22 +270,28 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     {
         TwV<Fr> t;
         // round 0: pairs (m, m + 4), twiddle index i0 + 32 m
+        if (skip < 1) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            load_tw2(t, s_tw, i0 + 32 * m);
-            bfly<Fr, PL.b[0], true, PL.red[0], false, 0>(e[m], e[m + 4], t.w, t.q);
+            for (int m = 0; m < 4; m++) {
+                load_tw2(t, s_tw, i0 + 32 * m);
+                bfly<Fr, PL.b[0], true, PL.red[0], false, 0>(e[m], e[m + 4], t.w, t.q);
+            }
         }
         // round 1: pairs (m, m + 2), twiddle index 2 (i0 + 32 (m & 1))
+        if (skip < 2) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            load_tw2(t, s_tw, 2 * (i0 + 32 * h));
-            bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h], e[h + 2], t.w, t.q);
-            bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h + 4], e[h + 6], t.w, t.q);
+            for (int h = 0; h < 2; h++) {
+                load_tw2(t, s_tw, 2 * (i0 + 32 * h));
+                bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h], e[h + 2], t.w, t.q);
+                bfly<Fr, PL.b[1], true, PL.red[1], false, 1>(e[h + 4], e[h + 6], t.w, t.q);
+            }
         }
         // round 2: pairs (m, m + 1), twiddle index 4 i0
-        load_tw2(t, s_tw, 4 * i0);
+        if (skip < 3) {
+            load_tw2(t, s_tw, 4 * i0);
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[2], true, PL.red[2], false, 0>(e[m], e[m + 1], t.w, t.q);
+            for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[2], true, PL.red[2], false, 0>(e[m], e[m + 1], t.w, t.q);
+        }
     }
 
     // ---- exchange 1: element (s, i) lives at word s | ((i[7:5] ^ i[1:0]) << 3) | (i[4:0] << 6) of each plane
@@ -295,10 +315,12 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
         const unsigned j0 = wave;
         const bool w0 = j0 == 0;
         TwV<Fr> t;
+        if (skip < 4) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
-            bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q, m == 0 && w0);
+            for (int m = 0; m < 4; m++) {
+                load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
+                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q, m == 0 && w0);
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -354,16 +376,15 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     const unsigned p = 1u << lgp, k = blk & (p - 1);
     const unsigned iq = brev(q, 5);
     if constexpr (LAST) {
-        size_t base;
-        if (A.br_out)
-            base = ((size_t)brev0(blk, lgp) << 8) + (q << 3);
-        else
-            base = ((size_t)(blk - k) << 8) + k + ((size_t)iq << lgp);
+        // the last pass has blk < 2^lgp: y[blk + i_out 2^lgp], or bit-reversed the run of sub-transform blk at bitrev(blk) 2^deg
+        const unsigned smask = (1u << skip) - 1, pmask = (1u << deg) - 1;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             fe_reduce_mad_2p(e[m]);
             fe_reduce_once(e[m]);
-            const size_t dst = A.br_out ? base + m : base + ((size_t)(br3(m) << 5) << lgp);
+            const unsigned v = (br3(m) << 5) | iq;                        // bitrev8 of the local index 8 q + m
+            const unsigned sub = blk0 + (brev0(v & smask, skip) << 3) + s; // its top `skip` bits, un-reversed, pick the sub-transform
+            const size_t dst = A.br_out ? ((size_t)brev0(sub, lgp) << deg) + ((8 * q + m) & pmask) : (size_t)sub + ((size_t)(v >> skip) << lgp);
             store_elem32(A.y + dst * 8, e[m]);
         }
     } else {
