@@ -7,7 +7,10 @@
 //   * the buffer protocol: ceil(log_n / 8) passes of radix 2^deg (deg = min(8, remaining), fft.cu:177,193-210),
 //     ping-pong between d_src and d_dst, *flag = passes & 1 tells the caller where the answer is (fft.cu:211,
 //     unit.rs:521-532).
-// and everything else is new:
+// and everything else is new.  Since round 3 the passes of transforms of 2^11 points and more live in ntt_radix8.h (k_ntt_pass8:
+// eight elements per thread in registers, three register blocks with two LDS exchanges, precomputed-quotient twiddle products, the
+// twiddle between passes on the output side; k_ntt_small: radix 2 / 4 / 8 passes without LDS).  This file keeps the host side -- tables,
+// pass loop, flag protocol, slab steps, C entry points -- and k_ntt_pass, the kernel of rounds 1-2, for transforms below 2^11 points:
 //   * one workgroup = one 1024-element tile (4 radix-256 sub-transforms) held in LDS as 9 limb planes, so a
 //     butterfly's 18 ds_read_b32 / ds_write_b32 are bank-conflict-free across the wave;
 //   * the residues stay in the caller's Montgomery radix (2^256): multiplying by a twiddle held in the
