@@ -893,14 +893,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
 
-    struct PhaseEvents { // destroyed on every exit path
-        hipEvent_t ev[8] = {};
+    struct PhaseEvents { // the per-range events are destroyed on every exit path
         std::vector<hipEvent_t> uploaded, fixed; // range r: its scalars have arrived / its buckets are in the total
         hipEvent_t started = nullptr;
         ~PhaseEvents()
         {
-            for (auto &e : ev)
-                if (e) (void)hipEventDestroy(e);
             for (auto &e : uploaded)
                 if (e) (void)hipEventDestroy(e);
             for (auto &e : fixed)
@@ -908,8 +905,31 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             if (started) (void)hipEventDestroy(started);
         }
     } phase_events;
-    hipEvent_t(&ev)[8] = phase_events.ev;
-    for (auto &e : ev) PANDA_TRY(hipEventCreate(&e));
+    // the eight phase-timer events are kept per host thread and device: creating and destroying them in every call was a
+    // measurable share of the host time of a 2^20-point call
+    struct TimerEvents {
+        hipEvent_t ev[8] = {};
+        int device = -1;
+        void drop()
+        {
+            for (auto &e : ev) {
+                if (e) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        }
+        ~TimerEvents() { drop(); }
+    };
+    static thread_local TimerEvents timer_events;
+    {
+        int dev = -1;
+        PANDA_TRY(hipGetDevice(&dev));
+        if (timer_events.device != dev) {
+            timer_events.drop();
+            for (auto &e : timer_events.ev) PANDA_TRY(hipEventCreate(&e));
+            timer_events.device = dev;
+        }
+    }
+    hipEvent_t(&ev)[8] = timer_events.ev;
     auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
 
     // upload of range r on the copy stream (a pageable source makes the call block until the range is staged, a pinned one returns at once)
