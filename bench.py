@@ -678,7 +678,15 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
 def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True) -> dict:
     """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26."""
     res = ntt_one(ctx, log_n, reps)
+    n24 = 1 << log_n
     res["metric"] = "NTT elements/s (BN254 Fr, 2^24, forward)"
+    if log_n == 24:
+        # what binds the passes (DESIGN.md section 5): v_mad_u64_u32 per thread (8 elements) and pass in k_ntt_pass8 -- 24.25 butterfly products
+        # (7 of wave 0's 12 middle-block products are skipped) + 8 / 16 / 0 output products of 143 each -- over the transform's device time
+        mads_per_element = (24.25 * 3 + 8 + 16) * 143 / 8
+        mads = n24 * mads_per_element / (res["ms"] * 1e-3)
+        res["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12, "unit": "T mad lane-ops/s",
+                                 "frac": mads / MAD_PEAK_PER_S, "mads_per_element": mads_per_element}
     res["timing"] = ("ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); "
                      "wall_ms = host time of the synchronous call")
     if sweep:
