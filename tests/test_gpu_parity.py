@@ -543,6 +543,51 @@ def test_c_abi_multi_gpu_ntt(gm, ranks, transport, log_n):
             d.free()
 
 
+def test_c_abi_multi_gpu_handles_from_two_threads(gm):
+    """Two panda_multi_gpu handles alive at once (two sets of worker threads), each driven from its own host thread while the other is
+    busy, created and destroyed three times over: every call returns the MSM of its own inputs."""
+    import threading
+    lib = ffi.load()
+    k, ranks = 14, 2
+    n, per = 1 << k, (1 << k) // ranks
+    problems = []
+    for t in range(2):
+        seed_b, seed_s = 0xAB00 + t, 0xCD00 + t
+        db, ds = DeviceBuffer(n * 64), DeviceBuffer(n * 32)
+        res = [DeviceBuffer(96) for _ in range(ranks)]
+        ffi.check(lib.panda_gen_bases(0, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+        ffi.check(lib.panda_gen_scalars(0, seed_s, 0, n, ds.ptr, NULL_STREAM), "gen")
+        want = po.expected_from_linearity(0, seed_b, ds.to_host().reshape(n, 8))
+        cfgs = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), C.c_void_p(db.ptr.value + r * per * 64), C.c_void_p(ds.ptr.value + r * per * 32),
+                                     res[r].ptr, k - 1, pgm.JACOBIAN) for r in range(ranks)]
+        problems.append((db, ds, res, cfgs, want))
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                mg = multi_gpu.MultiGpu([0] * ranks, ffi.MULTI_LOOPBACK)
+                try:
+                    for _ in range(4):
+                        total = mg.msm(problems[t][3])
+                        if not (affine_of(0, total) == problems[t][4]).all():
+                            errors.append(f"thread {t}: wrong sum")
+                finally:
+                    mg.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for db, ds, res, _, _ in problems:
+        for d in [db, ds] + res:
+            d.free()
+    assert not errors, errors
+
+
 def test_c_abi_multi_gpu_bad_arguments(gm):
     lib = ffi.load()
     h = ffi.PandaMultiGpu()
