@@ -388,4 +388,133 @@ PandaGpuError panda_intt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, 
     return run_ntt(gm, scalars, len, &omega, log_n, NttKind::Inverse);
 }
 
+// ------------------------------------------------------------------------------------------------ one process, several devices
+
+PandaGpuError PandaMultiGpuManager::create(const std::vector<int> &devices, unsigned transport, PandaMultiGpuManager *out)
+{
+    if (devices.empty()) return PandaGpuError::SetDeviceError;
+    out->devices_ = devices;
+    out->managers.resize(devices.size());
+    for (size_t d = 0; d < devices.size(); d++) {
+        PandaGpuError e = PandaGpuManager::create((size_t)devices[d], &out->managers[d]);
+        if (e != PandaGpuError::Ok) return e;
+    }
+    if (panda_multi_gpu_create(&out->handle, devices.data(), (unsigned)devices.size(), transport) != 0) return PandaGpuError::CreateContextError;
+    return set_device((size_t)devices[0]);
+}
+
+PandaGpuError PandaMultiGpuManager::deinit()
+{
+    PandaGpuError first = PandaGpuError::Ok;
+    if (handle.handle && panda_multi_gpu_destroy(handle) != 0) first = PandaGpuError::DestroyContextErr;
+    handle.handle = nullptr;
+    for (size_t d = 0; d < managers.size(); d++) {
+        if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) continue;
+        if (d < d_bases_.size() && d_bases_[d]) {
+            (void)panda_msm_unregister_bases(d_bases_[d]);
+            (void)panda_free(d_bases_[d]);
+        }
+        PandaGpuError e = managers[d].deinit();
+        if (first == PandaGpuError::Ok) first = e;
+    }
+    d_bases_.clear();
+    managers.clear();
+    return first;
+}
+
+PandaGpuError PandaMultiGpuManager::init_msm_cached_bases(Bytes bases, bool tables)
+{
+    const size_t G = managers.size(), n = (size_t)1 << log_2(bases.len / (2 * FIELD_ELEMENT_LEN));
+    if (n % G != 0) return PandaGpuError::SetBasesErr;
+    const size_t per = n / G;
+    if ((per & (per - 1)) != 0) return PandaGpuError::SetBasesErr; // every rank runs a power-of-two MSM
+    bases_log_per_ = log_2(per);
+    tables_ = tables;
+    d_bases_.assign(G, nullptr);
+    for (size_t d = 0; d < G; d++) {
+        if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+        if (panda_malloc(&d_bases_[d], per * 64) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        if (panda_memcpy(d_bases_[d], bases.data + d * per * 64, per * 64) != 0) return PandaGpuError::AsyncMemcopyErr;
+        const panda_error pe = tables ? panda_msm_precompute_bases(0, d_bases_[d], bases_log_per_, 0, managers[d].get_exec_stream())
+                                      : panda_msm_register_bases(0, d_bases_[d], bases_log_per_, managers[d].get_exec_stream());
+        if (pe != 0) return PandaGpuError::SetBasesErr;
+    }
+    return set_device((size_t)devices_[0]);
+}
+
+PandaGpuError PandaMultiGpuManager::msm_bn254_with_cached_bases(Bytes scalars, std::vector<uint8_t> *result)
+{
+    const size_t G = managers.size(), per = (size_t)1 << bases_log_per_;
+    if (d_bases_.size() != G || scalars.len < G * per * FIELD_ELEMENT_LEN) return PandaGpuError::BasesIndexErr;
+    struct Staged { // device scalars and results of every rank, freed on every way out
+        std::vector<void *> ptrs;
+        std::vector<int> dev;
+        ~Staged()
+        {
+            for (size_t i = 0; i < ptrs.size(); i++)
+                if (ptrs[i] && panda_set_device(dev[i]) == 0) (void)panda_free(ptrs[i]);
+        }
+    } staged;
+    std::vector<panda_msm_configuration> cfgs(G);
+    for (size_t d = 0; d < G; d++) {
+        if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+        void *ds = nullptr, *dr = nullptr;
+        if (panda_malloc(&ds, per * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        staged.ptrs.push_back(ds);
+        staged.dev.push_back(devices_[d]);
+        if (panda_malloc(&dr, 3 * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        staged.ptrs.push_back(dr);
+        staged.dev.push_back(devices_[d]);
+        if (panda_memcpy(ds, scalars.data + d * per * FIELD_ELEMENT_LEN, per * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
+        cfgs[d] = panda_msm_configuration{managers[d].get_mem_pool(), managers[d].get_exec_stream(), d_bases_[d], ds, dr, bases_log_per_,
+                                          managers[0].get_msm_result_coordinate_type()};
+    }
+    result->assign(3 * FIELD_ELEMENT_LEN, 0);
+    const bool ok = panda_msm_execute_bn254_multi(handle, cfgs.data(), result->data()) == 0;
+    (void)set_device((size_t)devices_[0]);
+    return ok ? PandaGpuError::Ok : PandaGpuError::SchedulingErr;
+}
+
+PandaGpuError PandaMultiGpuManager::ntt_bn254(uint8_t *data, size_t len, Bytes omega, uint32_t log_n)
+{
+    const size_t G = managers.size(), n = (size_t)1 << log_n;
+    uint32_t log_g = 0;
+    while (((size_t)1 << log_g) < G) log_g++;
+    if (((size_t)1 << log_g) != G || len < n * FIELD_ELEMENT_LEN || omega.len < FIELD_ELEMENT_LEN || log_n < 2 * log_g) return PandaGpuError::NttExecErr;
+    const size_t m = n / G, chunk = m / G;
+    struct Staged {
+        std::vector<void *> ptrs;
+        std::vector<int> dev;
+        ~Staged()
+        {
+            for (size_t i = 0; i < ptrs.size(); i++)
+                if (ptrs[i] && panda_set_device(dev[i]) == 0) (void)panda_free(ptrs[i]);
+        }
+    } staged;
+    std::vector<panda_ntt_slab_configuration> cfgs(G);
+    std::vector<unsigned> flags(G, 0);
+    std::vector<uint8_t> slab(m * FIELD_ELEMENT_LEN);
+    for (size_t d = 0; d < G; d++) { // rank d holds the decimated sequence x[d + G j]
+        for (size_t j = 0; j < m; j++) std::memcpy(slab.data() + j * FIELD_ELEMENT_LEN, data + (d + G * j) * FIELD_ELEMENT_LEN, FIELD_ELEMENT_LEN);
+        if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+        void *a = nullptr, *b = nullptr;
+        if (panda_malloc(&a, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        staged.ptrs.push_back(a);
+        staged.dev.push_back(devices_[d]);
+        if (panda_malloc(&b, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+        staged.ptrs.push_back(b);
+        staged.dev.push_back(devices_[d]);
+        if (panda_memcpy(a, slab.data(), m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
+        cfgs[d] = panda_ntt_slab_configuration{managers[d].get_exec_stream(), a, b, const_cast<uint8_t *>(omega.data), log_n, log_g, (unsigned)d, &flags[d]};
+    }
+    if (panda_ntt_execute_bn254_multi(handle, cfgs.data()) != 0) return PandaGpuError::NttExecErr;
+    for (size_t q = 0; q < G; q++) { // rank q holds y[k1 m + q m/G + k2'] at [k1][k2']
+        if (set_device((size_t)devices_[q]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+        if (panda_memcpy(slab.data(), flags[q] ? cfgs[q].d_scratch : cfgs[q].d_slab, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
+        for (size_t k1 = 0; k1 < G; k1++)
+            std::memcpy(data + (k1 * m + q * chunk) * FIELD_ELEMENT_LEN, slab.data() + k1 * chunk * FIELD_ELEMENT_LEN, chunk * FIELD_ELEMENT_LEN);
+    }
+    return set_device((size_t)devices_[0]);
+}
+
 } // namespace panda_host

@@ -137,4 +137,31 @@ PandaGpuError panda_ntt_bn254_gpu_v1(const PandaGpuManager &gm, uint8_t *scalars
 // additive: inverse transform with n^-1 fused
 PandaGpuError panda_intt_bn254_gpu(const PandaGpuManager &gm, uint8_t *scalars, size_t len, Bytes omega, uint32_t log_n);
 
+// Additive (no reference counterpart: wrapper.rs:38 opens ONE device): the sharded calls from host slices, one process.  One
+// PandaGpuManager per device stages that device's share exactly as the single-GPU calls do; the sharded operation itself is one C call
+// on a panda_multi_gpu handle (csrc/multi_gpu.hip: worker thread + RCCL communicator per device).
+class PandaMultiGpuManager {
+  public:
+    // transport: PANDA_MULTI_RCCL (one rank per device) or PANDA_MULTI_LOOPBACK (device copies; devices may repeat)
+    static PandaGpuError create(const std::vector<int> &devices, unsigned transport, PandaMultiGpuManager *out);
+    PandaGpuError deinit();
+    size_t ranks() const { return managers.size(); }
+    // cached bases: rank d keeps points [d n/G, (d+1) n/G) on its device, optionally with precomputed window tables
+    PandaGpuError init_msm_cached_bases(Bytes bases, bool tables);
+    // MSM of `scalars` against the cached bases: rank d gets its slice of the scalars; result = 96 bytes X||Y||Z
+    PandaGpuError msm_bn254_with_cached_bases(Bytes scalars, std::vector<uint8_t> *result);
+    // forward transform of 2^log_n elements given in natural order; `data` receives y in natural order (the slabs are decimated
+    // on the way in and the output layout y[k1 m + q m/G + k2'] at rank q's [k1][k2'] is undone on the way out)
+    PandaGpuError ntt_bn254(uint8_t *data, size_t len, Bytes omega, uint32_t log_n);
+
+    std::vector<PandaGpuManager> managers;
+    panda_multi_gpu handle{};
+
+  private:
+    std::vector<int> devices_;
+    std::vector<void *> d_bases_; // per rank
+    uint32_t bases_log_per_ = 0;
+    bool tables_ = false;
+};
+
 } // namespace panda_host

@@ -311,6 +311,46 @@ int main(int argc, char **argv)
                    transport == PANDA_MULTI_RCCL ? "RCCL" : "loopback");
         }
     }
+    { // the host-level wrapper a maintainer would write over those entry points: PandaMultiGpuManager (gpu_manager.hpp), from host slices
+        PandaMultiGpuManager mgm;
+        REQUIRE(PandaMultiGpuManager::create({0, 0}, PANDA_MULTI_LOOPBACK, &mgm) == PandaGpuError::Ok);
+        const unsigned k = 15;
+        const size_t n = (size_t)1 << k;
+        std::vector<uint8_t> bases(n * 64), scalars(n * 32), whole, sharded;
+        void *d = nullptr;
+        REQUIRE(panda_malloc(&d, n * 64) == 0);
+        REQUIRE(panda_gen_bases(0, 5100, 0, n, d, panda_stream{}) == 0);
+        REQUIRE(panda_memcpy(bases.data(), d, n * 64) == 0);
+        REQUIRE(panda_gen_scalars(0, 5200, 0, n, d, panda_stream{}) == 0);
+        REQUIRE(panda_memcpy(scalars.data(), d, n * 32) == 0);
+        REQUIRE(panda_free(d) == 0);
+        REQUIRE(panda_msm_bn254_gpu(gm, Bytes{scalars.data(), scalars.size()}, Bytes{bases.data(), bases.size()}, &whole) == PandaGpuError::Ok);
+        for (int tables = 0; tables < 2; tables++) {
+            REQUIRE(mgm.init_msm_cached_bases(Bytes{bases.data(), bases.size()}, tables != 0) == PandaGpuError::Ok);
+            REQUIRE(mgm.msm_bn254_with_cached_bases(Bytes{scalars.data(), scalars.size()}, &sharded) == PandaGpuError::Ok);
+            REQUIRE(affine_of(sharded, false) == affine_of(whole, false));
+            if (tables == 0) { // re-stage with tables: drop the first registration
+                PandaMultiGpuManager again;
+                REQUIRE(mgm.deinit() == PandaGpuError::Ok);
+                REQUIRE(PandaMultiGpuManager::create({0, 0}, PANDA_MULTI_LOOPBACK, &again) == PandaGpuError::Ok);
+                mgm = again;
+            }
+        }
+        const unsigned log_n = 13;
+        std::vector<uint8_t> x((size_t)32 << log_n), y;
+        REQUIRE(panda_malloc(&d, x.size()) == 0);
+        REQUIRE(panda_gen_scalars(0, 5300, 0, (size_t)1 << log_n, d, panda_stream{}) == 0);
+        REQUIRE(panda_memcpy(x.data(), d, x.size()) == 0);
+        REQUIRE(panda_free(d) == 0);
+        u32 omega[8];
+        root_of_unity(omega, log_n);
+        y = x;
+        REQUIRE(panda_ntt_bn254_gpu_v1(gm, y.data(), y.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+        REQUIRE(mgm.ntt_bn254(x.data(), x.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+        REQUIRE(x == y);
+        REQUIRE(mgm.deinit() == PandaGpuError::Ok);
+        printf("PandaMultiGpuManager: sharded MSM 2^15 (registered and tabled) and NTT 2^13 from host slices ok\n");
+    }
     REQUIRE(gm.deinit() == PandaGpuError::Ok);
     printf("manager_test: all ok\n");
     return 0;
