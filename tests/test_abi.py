@@ -39,6 +39,19 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.panda_version()
 
 
+def test_multi_gpu_entry_points_link_rccl():
+    """The single-process multi-GPU entry points (csrc/multi_gpu.hip) are part of the library and the exchange they issue is RCCL's:
+    the shared object names librccl among its dependencies and imports the collectives it calls; the handle is one pointer."""
+    dyn = subprocess.run(["readelf", "-d", ffi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert re.search(r"NEEDED.*librccl\.so", dyn), dyn
+    und = subprocess.run(["nm", "-D", "--undefined-only", ffi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    for sym in ("ncclCommInitAll", "ncclAllGather", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
+        assert re.search(rf"\b{sym}\b", und), sym
+    assert C.sizeof(ffi.PandaMultiGpu) == C.sizeof(C.c_void_p)
+    for s in ("panda_multi_gpu_create", "panda_msm_execute_bn254_multi", "panda_ntt_execute_bn254_multi", "panda_ntt_execute_bn254_inverse_multi"):
+        assert s in ffi.ADDITIVE_SYMBOLS
+
+
 def test_static_library_is_built_too():
     a = os.path.join(os.path.dirname(ffi.LIB_PATH), "libpanda-cuda.a")
     assert os.path.exists(a)  # `cargo:rustc-link-lib=static=panda-cuda`, build.rs:45
