@@ -188,8 +188,11 @@ panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configur
 
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
 panda_error panda_msm_set_window_bits(unsigned window_bits);
-/* buckets per thread in the bucket-reduction kernel, for experiments: 0 = built-in policy */
-panda_error panda_msm_set_reduce_group(unsigned group);
+/* sorted entries per thread of the bucket-accumulation kernel, for experiments: 0 = built-in policy (rounded up to a multiple of 4) */
+panda_error panda_msm_set_chunk_entries(unsigned entries);
+/* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = the call's total only,
+ * 1 = total + the bucket-accumulation kernel (default), 2 = every phase.  Phases that were not timed read 0 in panda_msm_last_phase_ms. */
+panda_error panda_msm_set_phase_timing(unsigned level);
 /* per-phase device times of the last MSM on this thread, milliseconds; names via panda_msm_phase_name */
 #define PANDA_MSM_PHASES 8
 panda_error panda_msm_last_phase_ms(float *ms /* PANDA_MSM_PHASES floats */);

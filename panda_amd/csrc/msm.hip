@@ -172,7 +172,8 @@ size_t forget_if(Pred pred)
 }
 
 std::atomic<unsigned> g_window_override{0};
-std::atomic<unsigned> g_reduce_group{0};
+std::atomic<unsigned> g_chunk{0};
+std::atomic<unsigned> g_phase_timing{1};
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
@@ -209,7 +210,8 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 
 hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale, const panda::MsmPipeline *pipe)
 {
-    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_reduce_group.load(std::memory_order_relaxed)};
+    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
+                                  g_phase_timing.load(std::memory_order_relaxed)};
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
     case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
@@ -363,10 +365,17 @@ panda_error panda_msm_set_window_bits(unsigned window_bits)
     return panda_success;
 }
 
-panda_error panda_msm_set_reduce_group(unsigned group)
+panda_error panda_msm_set_chunk_entries(unsigned entries)
 {
-    if (group > 64) return panda_error_invalid_value;
-    g_reduce_group.store(group, std::memory_order_relaxed);
+    if (entries > 1024) return panda_error_invalid_value;
+    g_chunk.store(entries, std::memory_order_relaxed);
+    return panda_success;
+}
+
+panda_error panda_msm_set_phase_timing(unsigned level)
+{
+    if (level > 2) return panda_error_invalid_value;
+    g_phase_timing.store(level, std::memory_order_relaxed);
     return panda_success;
 }
 

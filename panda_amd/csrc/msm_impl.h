@@ -23,8 +23,7 @@
 //   msm_sort.hip      scalars -> signed window digits -> per-bucket lists of base indices (two or three LDS-staged sort levels)
 //   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
 //   k_fixup           merge bucket pieces that straddle chunks
-//   k_reduce_groups   running sums over groups of buckets
-//   k_bit_sums/k_bit_finish (several lists) or k_rowcol_sums/k_bit_sums2 (one large list), k_slot_sum
+//   k_sum_lines / k_weighted_finish
 //                     weighted sum of the group sums -> one point per list
 //   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743) -- none with precomputed
 //                     tables, whose single list already carries the 2^lo[k] factors -- and output conversion
@@ -32,7 +31,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "curve29.h"
+#include "curve29_quad.h"
 #include "msm_sort.h"
 #include "panda_internal.h"
 
@@ -53,7 +52,8 @@ constexpr unsigned REG_SAMPLES = 64;
 
 struct MsmTuning {
     unsigned window_bits;  // plain-mode window width (already resolved by the policy)
-    unsigned reduce_group; // 0 = built-in
+    unsigned chunk;        // sorted entries per k_accumulate thread, 0 = built-in
+    unsigned timing;       // 0: total device time only; 1: + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -236,6 +236,36 @@ __device__ __forceinline__ void xyzz_dbl_k(Xyzz<F> &r, const Xyzz<F> &p)
         xyzz_dbl(r, p);
 }
 
+// Four-lane spellings (curve29_quad.h) for the trees behind k_accumulate, where waves run alone on their SIMD and a level of the
+// tree costs one addition's latency: 3.4 us instead of 7.3 (profiles/r04_ubench_addlat.txt).  role = lane & 3; operands and result
+// are replicated over the quad.
+template <class F>
+__device__ __noinline__ void xyzz_add_quad_outlined(Xyzz<F> &acc, const Xyzz<F> &q, unsigned role)
+{
+    xyzz_add_quad(acc, q, role);
+}
+template <class F>
+__device__ __noinline__ void xyzz_dbl_quad_outlined(Xyzz<F> &r, const Xyzz<F> &p, unsigned role)
+{
+    xyzz_dbl_quad(r, p, role);
+}
+template <class F>
+__device__ __forceinline__ void xyzz_add_q(Xyzz<F> &acc, const Xyzz<F> &q, unsigned role)
+{
+    if constexpr (IsExt2<F>::value)
+        xyzz_add_quad_outlined(acc, q, role);
+    else
+        xyzz_add_quad(acc, q, role);
+}
+template <class F>
+__device__ __forceinline__ void xyzz_dbl_q(Xyzz<F> &r, const Xyzz<F> &p, unsigned role)
+{
+    if constexpr (IsExt2<F>::value)
+        xyzz_dbl_quad_outlined(r, p, role);
+    else
+        xyzz_dbl_quad(r, p, role);
+}
+
 // Rows of the caller's wire buffer remembered at registration and compared on every execute (msm.hip, "Staleness").
 // Sample t is row 0, row n-1, or a fixed pseudo-random row; block = REG_SAMPLES x 16 threads, lane l owns words l, l+16, ...
 __device__ __forceinline__ u64 sample_row(unsigned t, u64 n) { return t == 0 ? 0 : (t == 1 ? n - 1 : (((u64)t * 0x9E3779B97F4A7C15ull) >> 20) & (n - 1)); }
@@ -314,12 +344,13 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 template <class F>
 __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
-                                                    unsigned chunks)
+                                                    unsigned chunks, u32 *__restrict__ long_count)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunks) return;
+    if (t == 0) long_count[w] = 0; // the fix-up's queue of long buckets starts empty (it runs behind this kernel on the same stream)
     const u32 *ow = off + (u64)w * (NB + 1);
     const u32 nw = ow[NB];
     const u32 start = t * K;
@@ -421,18 +452,26 @@ constexpr unsigned LONG_BLOCKS = 256; // workgroups per window that serve the qu
 // MERGE (point-range chunks, every range after the first): `bucket_acc` holds this range's buckets -- only the non-empty ones are
 // defined -- and every non-empty bucket is added into `total`, the running sum over the ranges, here instead of in a pass of its own.
 template <class F, bool MERGE>
-__global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, u32 *__restrict__ total,
-                                               unsigned NB, unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
+__global__ void __launch_bounds__(256) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, u32 *__restrict__ total,
+                                               unsigned NB, unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap,
+                                               u32 *__restrict__ tickets)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
     const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
+    if (b == 0) tickets[w] = 0; // k_weighted_finish, which runs behind every fix-up of the call, counts its finished workgroups here
     const u32 *ow = off + (u64)w * (NB + 1);
     const u32 s = ow[b], e = ow[b + 1];
-    if (s == e) return; // empty: bucket_acc was zeroed (identity) / nothing to add to the total
-    const u32 t0 = s / K, t1 = (e - 1) / K;
     Xyzz<F> acc, q;
+    if (s == e) { // empty: nothing to add to the total; the first range's bucket array is defined here (it is never zero-filled)
+        if (!MERGE) {
+            xyzz_set_identity(acc);
+            store_xyzz<F>(bucket_acc + ((u64)w * NB + b) * PW, acc);
+        }
+        return;
+    }
+    const u32 t0 = s / K, t1 = (e - 1) / K;
     if (t0 == t1) { // lies inside one chunk: written by k_accumulate
         if (!MERGE) return;
         load_xyzz<F>(acc, bucket_acc + ((u64)w * NB + b) * PW);
@@ -446,6 +485,7 @@ __global__ void __launch_bounds__(128) k_fixup(const u32 *__restrict__ off, cons
         }
         return;
     } else {
+        // (loading the piece of chunk t + 1 under the addition of chunk t's changes nothing: these waves are bound by the additions)
         const u32 *pw = parts + (u64)w * chunks * 2 * PW;
         load_xyzz<F>(acc, pw + ((u64)t0 * 2 + 1) * PW);
         for (u32 t = t0 + 1; t <= t1; t++) {
@@ -502,232 +542,148 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
 }
 
 // ---- bucket reduction: sum over b of (b+1) * B_b per list ------------------------------------------------------------
-// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420 (~240 mulmods per bucket) with
-//   k_reduce_groups  thread g takes `group` buckets: running sums from the top give S_g = sum B_j and
-//                    T_g = sum (j+1) B_j (j local) -- two additions per bucket.  The list's value is
-//                    sum_g T_g + group * sum_g g * S_g.
-//   k_bit_sums       the weighted sum over g is taken bit by bit: slot 1+j adds up the S_g whose index has bit j
-//                    set, slot 0 adds up all T_g; plain tree reductions, no scalar multiplications.
-//   k_bit_finish     slot 1+j is doubled (j + log2 group) times;  k_slot_sum adds the slots up.
+// Replaces the per-bucket c-step double-and-add of msm_cuda.cuh:411-420 (~240 mulmods per bucket).  The bucket index is split
+// b = hi * cols + lo (rows = 2^a values of hi, cols = 2^b of lo), so that
+//     sum_b (b + 1) B_b  =  sum_hi R_hi  +  cols * sum_hi hi * R_hi  +  sum_lo lo * C_lo,     R_hi = sum_lo B_{hi,lo},  C_lo = sum_hi B_{hi,lo}:
+//   k_sum_lines        row sums and column sums are PLAIN sums, two additions per bucket in all and no dependent chain longer than a
+//                      line; one wave per line (or per segment of a column, when columns are longer than rows).
+//   k_weighted_finish  the two short weighted sums are taken bit by bit: slot 1+j adds up the R_hi (C_lo) whose index has bit j set
+//                      and is doubled j + b (j) times, slot 0 adds up all R_hi; the last workgroup of a list to finish adds the
+//                      list's slots up.  No scalar multiplications anywhere.
+// (Rounds 1-3 first took running sums over groups of 4-8 buckets -- S_g, T_g, two additions per bucket as well -- and split the GROUP
+// index: one more kernel and 8-16 more dependent additions in front of the same trees.)
+// Everything here is a tree of dependent additions on a few waves: its time is (levels) x (latency of one addition), whatever the
+// input size.  A wave's sums therefore run as: every lane adds up its share, the 64 partial sums go through LDS to sixteen quads, and
+// the quads finish with four-lane additions (wave_reduce; curve29_quad.h: 3.4 us per level instead of 7.3).
+// 64-thread workgroup: lane-wise partial sums `acc` -> their total, replicated over quad 0 (lanes 0..3).  lds: 64 points.
 template <class F>
-__global__ void __launch_bounds__(128) k_reduce_groups(const u32 *__restrict__ bucket_acc, u32 *__restrict__ gS, u32 *__restrict__ gT, unsigned NB,
-                                                       unsigned groups, unsigned group)
+__device__ __forceinline__ void wave_reduce(Xyzz<F> &acc, u32 *lds, unsigned lane)
 {
     constexpr int PW = 4 * F::N;
-    const unsigned w = blockIdx.y;
-    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
-    const u32 *bw = bucket_acc + (u64)w * NB * PW;
-    Xyzz<F> run, sum, q;
-    xyzz_set_identity(run);
-    xyzz_set_identity(sum);
-#pragma unroll 1
-    for (int j = (int)group - 1; j >= 0; j--) {
-        u32 b = g * group + j;
-        if (b < NB) {
-            load_xyzz<F>(q, bw + (u64)b * PW);
-            xyzz_add_k(run, q);
-        }
-        xyzz_add_k(sum, run);
-    }
-    store_xyzz<F>(gS + ((u64)w * groups + g) * PW, run);
-    store_xyzz<F>(gT + ((u64)w * groups + g) * PW, sum);
-}
-
-// block (blk, slot, w): partial sum of its share of the slot's operands -> out[w][slot][blk]
-template <class F>
-__global__ void __launch_bounds__(256) k_bit_sums(const u32 *__restrict__ gS, const u32 *__restrict__ gT, u32 *__restrict__ out, unsigned groups, unsigned slots,
-                                                  unsigned nblk)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned blk = blockIdx.x, slot = blockIdx.y, w = blockIdx.z, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    if (slot == 0) {
-        const u32 *src = gT + (u64)w * groups * PW;
-        for (unsigned g = blk * 256 + t; g < groups; g += nblk * 256) {
-            load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add_k(acc, q);
-        }
-    } else {
-        const unsigned j = slot - 1;
-        const u32 *src = gS + (u64)w * groups * PW;
-        const u32 low = (1u << j) - 1;
-        for (unsigned i = blk * 256 + t;; i += nblk * 256) { // i-th index with bit j set
-            const unsigned g = ((i & ~low) << 1) | (1u << j) | (i & low);
-            if (g >= groups) break; // g grows with i
-            load_xyzz<F>(q, src + (u64)g * PW);
-            xyzz_add_k(acc, q);
-        }
-    }
-    store_xyzz<F>(lds + t * PW, acc);
+    const unsigned quad = lane >> 2, role = lane & 3u;
+    Xyzz<F> q;
+    store_xyzz<F>(lds + lane * PW, acc);
     __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add_k(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
+    load_xyzz<F>(acc, lds + (4 * quad) * PW);
+#pragma unroll 1
+    for (unsigned k = 1; k < 4; k++) {
+        load_xyzz<F>(q, lds + (4 * quad + k) * PW);
+        xyzz_add_q(acc, q, role);
     }
-    if (t == 0) store_xyzz<F>(out + (((u64)w * slots + slot) * nblk + blk) * PW, acc);
+#pragma unroll 1
+    for (unsigned s = 8; s > 0; s >>= 1) {
+        __syncthreads(); // the slots written below were read above / in the previous level
+        if (quad >= s && quad < 2 * s && role == 0) store_xyzz<F>(lds + quad * PW, acc);
+        __syncthreads();
+        if (quad < s) {
+            load_xyzz<F>(q, lds + (quad + s) * PW);
+            xyzz_add_q(acc, q, role);
+        }
+    }
 }
 
-// block (slot, w), 64 threads: tree over the slot's nblk partials, then slot 1+j is doubled (j + log2 group) times
+// workgroup (x, list), one wave.  x < rows: row x;  else segment (x - rows) / cols of column (x - rows) % cols (csplit segments of
+// rows / csplit buckets each: with rows = 2 cols a column is cut in two, so that every line is cols buckets long)
 template <class F>
-__global__ void __launch_bounds__(64) k_bit_finish(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots, unsigned nblk, unsigned log_group)
+__global__ void __launch_bounds__(64) k_sum_lines(const u32 *__restrict__ bucket_acc, u32 *__restrict__ outR, u32 *__restrict__ outC, unsigned rows, unsigned cols,
+                                                  unsigned csplit)
 {
     constexpr int PW = 4 * F::N;
     __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
-    const unsigned slot = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    const unsigned x = blockIdx.x, list = blockIdx.y, lane = threadIdx.x;
+    const u64 NB = (u64)rows * cols;
+    const u32 *src;
+    u32 *dst;
+    unsigned count, stride;
+    if (x < rows) {
+        src = bucket_acc + (list * NB + (u64)x * cols) * PW;
+        count = cols;
+        stride = 1;
+        dst = outR + ((u64)list * rows + x) * PW;
+    } else {
+        const unsigned seg = (x - rows) / cols, lo = (x - rows) % cols;
+        count = rows / csplit;
+        src = bucket_acc + (list * NB + (u64)seg * count * cols + lo) * PW;
+        stride = cols;
+        dst = outC + ((u64)list * cols * csplit + (x - rows)) * PW;
+    }
+    // (measured and dropped: the next bucket loaded under the addition of the current one, and every line starting its sweep at a
+    // different place -- whichever of the row and column passes runs first after the fix-up takes 1.4x as long as the other)
     Xyzz<F> acc, q;
     xyzz_set_identity(acc);
-    for (unsigned b = t; b < nblk; b += 64) {
-        load_xyzz<F>(q, in + (((u64)w * slots + slot) * nblk + b) * PW);
+#pragma unroll 1
+    for (unsigned i = lane; i < count; i += 64) {
+        load_xyzz<F>(q, src + (u64)i * stride * PW);
         xyzz_add_k(acc, q);
     }
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 32; s > 0; s >>= 1) {
-        if (t < s && t + s < nblk) { // partials beyond nblk are the identity
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add_k(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const unsigned doublings = slot ? (slot - 1 + log_group) : 0;
-#pragma unroll 1
-        for (unsigned d = 0; d < doublings; d++) {
-            xyzz_dbl_k(q, acc);
-            acc = q;
-        }
-        store_xyzz<F>(out + ((u64)w * slots + slot) * PW, acc);
-    }
+    wave_reduce<F>(acc, lds, lane);
+    if (lane == 0) store_xyzz<F>(dst, acc);
 }
 
-// Large bucket spaces (one list of up to 2^22 buckets): the group index is split g = hi * cols + lo, so that
-//   sum_g g S_g = cols * sum_hi hi * R_hi + sum_lo lo * C_lo,   R_hi = sum_lo S_{hi,lo},  C_lo = sum_hi S_{hi,lo}.
-// Row and column sums are plain sums (two additions per group instead of log2(groups)/2 in k_bit_sums); the two small
-// weighted sums that remain are taken bit by bit in k_bit_sums2.
-// block x < rows: row x;  rows <= x < rows + cols: column x - rows;  else: sum of the T_g of row x - rows - cols
+// workgroup (slot, list, part), one wave.  slot 0: sum of the R_hi;  slot 1+j (j < a): the R_hi with bit j of hi set, doubled j + b
+// times;  slot 1+a+j (j < b): the column (segment) sums with bit j of lo set, doubled j times (rows = 2^a, cols = 2^b).  A slot's
+// entries are shared out over `parts` workgroups, each of which doubles its own partial sum (2^k (x + y) = 2^k x + 2^k y: the doublings
+// of the parts run side by side).  The workgroup that finishes last (tickets[list]) adds the list's slots * parts partial sums up
+// into win[list].
 template <class F>
-__global__ void __launch_bounds__(256) k_rowcol_sums(const u32 *__restrict__ gS, const u32 *__restrict__ gT, u32 *__restrict__ outR, u32 *__restrict__ outC,
-                                                     u32 *__restrict__ outT, unsigned rows, unsigned cols)
+__global__ void __launch_bounds__(64) k_weighted_finish(const u32 *__restrict__ inR, const u32 *__restrict__ inC, u32 *slot_out, u32 *__restrict__ win, u32 *tickets,
+                                                        unsigned a, unsigned b, unsigned csplit)
 {
     constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned x = blockIdx.x, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    u32 *dst;
-    if (x < rows) {
-        for (unsigned lo = t; lo < cols; lo += 256) {
-            load_xyzz<F>(q, gS + ((u64)x * cols + lo) * PW);
-            xyzz_add_k(acc, q);
-        }
-        dst = outR + (u64)x * PW;
-    } else if (x < rows + cols) {
-        const unsigned lo = x - rows;
-        for (unsigned hi = t; hi < rows; hi += 256) {
-            load_xyzz<F>(q, gS + ((u64)hi * cols + lo) * PW);
-            xyzz_add_k(acc, q);
-        }
-        dst = outC + (u64)lo * PW;
-    } else {
-        const unsigned hi = x - rows - cols;
-        for (unsigned lo = t; lo < cols; lo += 256) {
-            load_xyzz<F>(q, gT + ((u64)hi * cols + lo) * PW);
-            xyzz_add_k(acc, q);
-        }
-        dst = outT + (u64)hi * PW;
-    }
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add_k(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
-    }
-    if (t == 0) store_xyzz<F>(dst, acc);
-}
-
-// slot 0: sum of outT;  slot 1+j (j < a): the R_hi with bit j of hi set, doubled j + b + log_group times;
-// slot 1+a+j (j < b): the C_lo with bit j of lo set, doubled j + log_group times.  One block per slot.
-template <class F>
-__global__ void __launch_bounds__(256) k_bit_sums2(const u32 *__restrict__ inR, const u32 *__restrict__ inC, const u32 *__restrict__ inT, u32 *__restrict__ out,
-                                                   unsigned a, unsigned b, unsigned log_group)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[256 * PW];
-    const unsigned slot = blockIdx.x, t = threadIdx.x;
-    const unsigned rows = 1u << a, cols = 1u << b;
+    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
+    __shared__ u32 ticket;
+    const unsigned slot = blockIdx.x, list = blockIdx.y, part = blockIdx.z, parts = gridDim.z, lane = threadIdx.x, role = lane & 3u;
+    const unsigned rows = 1u << a, cols = 1u << b, slots = 1 + a + b, partials = slots * parts;
     Xyzz<F> acc, q;
     xyzz_set_identity(acc);
     unsigned doublings = 0;
     if (slot == 0) {
-        for (unsigned i = t; i < rows; i += 256) {
-            load_xyzz<F>(q, inT + (u64)i * PW);
+        const u32 *src = inR + (u64)list * rows * PW;
+        const unsigned per = (rows + parts - 1) / parts, end = min(rows, (part + 1) * per);
+#pragma unroll 1
+        for (unsigned i = part * per + lane; i < end; i += 64) {
+            load_xyzz<F>(q, src + (u64)i * PW);
             xyzz_add_k(acc, q);
         }
     } else {
         const bool row_slot = slot <= a;
         const unsigned j = row_slot ? slot - 1 : slot - 1 - a;
-        const unsigned count = row_slot ? rows : cols;
-        const u32 *src = row_slot ? inR : inC;
-        doublings = j + log_group + (row_slot ? b : 0u);
-        for (unsigned i = t; i < count; i += 256)
-            if ((i >> j) & 1u) {
-                load_xyzz<F>(q, src + (u64)i * PW);
-                xyzz_add_k(acc, q);
-            }
-    }
-    store_xyzz<F>(lds + t * PW, acc);
-    __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
+        // entries: rows row sums, or csplit * cols column-segment sums (entry e belongs to column e % cols: bit j of e is bit j of lo)
+        const unsigned half = (row_slot ? rows : cols * csplit) >> 1; // entries whose index has bit j set
+        const u32 *src = row_slot ? inR + (u64)list * rows * PW : inC + (u64)list * cols * csplit * PW;
+        const u32 low = (1u << j) - 1;
+        const unsigned per = (half + parts - 1) / parts, end = min(half, (part + 1) * per);
+        doublings = j + (row_slot ? b : 0u);
+#pragma unroll 1
+        for (unsigned i = part * per + lane; i < end; i += 64) {
+            const unsigned idx = ((i & ~low) << 1) | (1u << j) | (i & low);
+            load_xyzz<F>(q, src + (u64)idx * PW);
             xyzz_add_k(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
         }
-        __syncthreads();
     }
-    if (t == 0) {
+    wave_reduce<F>(acc, lds, lane);
+    if (lane < 4) {
 #pragma unroll 1
         for (unsigned d = 0; d < doublings; d++) {
-            xyzz_dbl_k(q, acc);
+            xyzz_dbl_q(q, acc, role);
             acc = q;
         }
-        store_xyzz<F>(out + (u64)slot * PW, acc);
+        if (lane == 0) store_xyzz<F>(slot_out + ((u64)list * partials + slot * parts + part) * PW, acc);
     }
-}
-
-// block w, 64 threads: sum of the list's slots -> one point per list
-template <class F>
-__global__ void __launch_bounds__(64) k_slot_sum(const u32 *__restrict__ in, u32 *__restrict__ out, unsigned slots)
-{
-    constexpr int PW = 4 * F::N;
-    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
-    const unsigned w = blockIdx.x, t = threadIdx.x;
-    Xyzz<F> acc, q;
-    xyzz_set_identity(acc);
-    if (t < slots) load_xyzz<F>(acc, in + ((u64)w * slots + t) * PW);
-    store_xyzz<F>(lds + t * PW, acc);
+    __threadfence();
     __syncthreads();
-    for (unsigned s = 32; s > 0; s >>= 1) {
-        if (t < s && t + s < slots) {
-            load_xyzz<F>(q, lds + (t + s) * PW);
-            xyzz_add_k(acc, q);
-            store_xyzz<F>(lds + t * PW, acc);
-        }
-        __syncthreads();
+    if (lane == 0) ticket = atomicAdd(&tickets[list], 1u);
+    __syncthreads();
+    if (ticket != partials - 1) return; // uniform over the workgroup
+    __threadfence(); // the other workgroups' partial sums are visible from here on
+    xyzz_set_identity(acc);
+#pragma unroll 1
+    for (unsigned i = lane; i < partials; i += 64) {
+        load_xyzz<F>(q, slot_out + ((u64)list * partials + i) * PW);
+        xyzz_add_k(acc, q);
     }
-    if (t == 0) store_xyzz<F>(out + (u64)w * PW, acc);
+    wave_reduce<F>(acc, lds, lane);
+    if (lane == 0) store_xyzz<F>(win + (u64)list * PW, acc);
 }
 
 // Precomputed window tables for cached bases (the reference left the idea as a stub,
@@ -833,23 +789,17 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         // (a 2^21-point range at K = 128 kept three waves per SIMD busy: 2.4 ms instead of 1.8); 64 ... 256 measure the same at 2^24
         const u64 per_k = ((u64)lists * g.stride) >> 20;
         g.K = per_k >= 128 ? 128 : (per_k >= 64 ? 64 : (per_k >= 32 ? 32 : 16));
+        if (tuning.chunk) g.K = std::min(std::max((tuning.chunk + 3u) & ~3u, 4u), 1024u); // multiples of four: chunks start on 16 bytes
         g.chunks = (unsigned)((g.stride + g.K - 1) / g.K);
         g.long_cap = g.chunks / LONG_SPAN + 2;
         return g;
     };
-    unsigned log_group = NB >= (1u << 18) ? 3u : 2u; // log2 of the buckets per k_reduce_groups thread
-    if (tuning.reduce_group) log_group = floor_log2(tuning.reduce_group);
-    const unsigned group = 1u << log_group;
-    const unsigned groups = (NB + group - 1) / group;
-    unsigned slots = 1; // slot 0: the T_g; slot 1+j: the S_g whose index has bit j set
-    while ((1u << (slots - 1)) < groups) slots++;
-    const unsigned nblk = std::min(std::max(groups / 2048u, 1u), 64u); // blocks per slot in k_bit_sums
-    if (slots > 64) return hipErrorInvalidValue;
-    // one large list: row/column decomposition of the group index (k_rowcol_sums) instead of k_bit_sums
-    const bool rowcol = lists == 1 && groups >= (1u << 14) && (groups & (groups - 1)) == 0;
-    const unsigned rc_b = rowcol ? floor_log2(groups) / 2 : 0, rc_a = rowcol ? floor_log2(groups) - rc_b : 0;
-    const unsigned rc_rows = 1u << rc_a, rc_cols = 1u << rc_b;
-    if (rowcol) slots = 1 + rc_a + rc_b;
+    // row / column split of the bucket index: b = hi * cols + lo, rows = 2^a >= cols = 2^b; columns of 2 cols buckets are summed in two halves
+    const unsigned rc_b = (c - 1) / 2, rc_a = (c - 1) - rc_b;
+    const unsigned rc_rows = 1u << rc_a, rc_cols = 1u << rc_b, rc_csplit = rc_a > rc_b ? 2u : 1u;
+    const unsigned slots = 1 + rc_a + rc_b; // slot 0: all rows; then one per bit of hi and of lo
+    // workgroups per slot of k_weighted_finish: at most four entries per lane (2^21 buckets: 1024 of the 2048 row sums per slot)
+    const unsigned rc_parts = std::max(1u, std::max(rc_rows, rc_cols * rc_csplit) / 512u);
 
     // ---- scratch
     const size_t sz_bases = registered ? 0 : panda::align256(n * 2 * LQ * 4);
@@ -862,17 +812,17 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         sz_llist = std::max(sz_llist, panda::align256((size_t)lists * g.long_cap * 3 * 4));
     }
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
-    const size_t sz_gsum = panda::align256((size_t)lists * groups * PW * 4);
-    const size_t sz_l1 = panda::align256(std::max((size_t)lists * slots * nblk, (size_t)2 * rc_rows + rc_cols) * PW * 4);
+    const size_t sz_l1 = panda::align256((size_t)lists * (rc_rows + rc_cols * rc_csplit) * PW * 4);
     const size_t sz_win = panda::align256((size_t)lists * PW * 4 + 4); // + the stale-registration flag, fetched with the window sums
-    const size_t sz_slots = panda::align256((size_t)lists * slots * PW * 4);
+    const size_t sz_tickets = panda::align256((size_t)lists * 4);
+    const size_t sz_slots = panda::align256((size_t)lists * slots * rc_parts * PW * 4);
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
     panda::Arena &arena = panda::thread_arena();
     // Ranges alternate between two lanes -- the caller's stream and a helper stream of this host thread -- each with its own sort
     // scratch, pieces and range buckets, so that range r+1 is sorted (LDS / HBM work) while range r is still being accumulated
     // (vector issue); the fix-ups, which all add into the one total, are chained by events.
     const unsigned lanes = nranges > 1 ? 2u : 1u;
-    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + 2 * sz_gsum + sz_l1 + sz_win + sz_slots + 8192));
+    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + sz_l1 + sz_win + sz_slots + sz_tickets + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
     u32 *d_bacc_range[2] = {d_bacc, d_bacc}, *d_parts_l[2] = {nullptr, nullptr}, *d_lcount_l[2] = {nullptr, nullptr}, *d_llist_l[2] = {nullptr, nullptr};
@@ -883,12 +833,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         d_llist_l[l] = (u32 *)arena.take(sz_llist);
         if (!d_bacc_range[l] || !d_parts_l[l] || !d_lcount_l[l] || !d_llist_l[l]) return hipErrorOutOfMemory;
     }
-    u32 *d_gsum = (u32 *)arena.take(sz_gsum);
-    u32 *d_gtsum = (u32 *)arena.take(sz_gsum);
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_win = (u32 *)arena.take(sz_win);
     u32 *d_slots = (u32 *)arena.take(sz_slots);
-    if (!d_bases || !d_bacc || !d_gsum || !d_gtsum || !d_l1 || !d_win || !d_slots) return hipErrorOutOfMemory;
+    u32 *d_tickets = (u32 *)arena.take(sz_tickets);
+    if (!d_bases || !d_bacc || !d_l1 || !d_win || !d_slots || !d_tickets) return hipErrorOutOfMemory;
     const size_t sort_mark[2] = {arena.used, arena.used + panda::align256(sz_sort) + 512}; // a lane's sorts carve their scratch from its mark again
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
@@ -930,7 +879,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         }
     }
     hipEvent_t(&ev)[8] = timer_events.ev;
-    auto mark = [&](int i) { return hipEventRecord(ev[i], stream); };
+    // which of the eight events a call records: an event between two kernels keeps the GPU idle for ~6 us (rocprofv3 timeline of a
+    // 2^20-point call, profiles/r04_*), so only the level the caller asked for is paid for
+    const unsigned timing = tuning.timing;
+    auto wanted = [&](int i) { return i == 0 || i >= 6 || (timing >= 1 && (i == 3 || i == 4)) || timing >= 2; };
+    auto mark = [&](int i) { return wanted(i) ? hipEventRecord(ev[i], stream) : hipSuccess; };
 
     // upload of range r on the copy stream (a pageable source makes the call block until the range is staged, a pinned one returns at once)
     const char *h_scalars = pipe ? (const char *)pipe->h_scalars : nullptr;
@@ -968,7 +921,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         if (h_scalars) PANDA_TRY(hipStreamWaitEvent(ls, phase_events.uploaded[r], 0));
         arena.used = sort_mark[lane];
         panda::SortResult sorted{};
-        const panda::SortEvents sort_events{last ? ev[1] : nullptr, last ? ev[2] : nullptr};
+        const panda::SortEvents sort_events{last && wanted(1) ? ev[1] : nullptr, last && wanted(2) ? ev[2] : nullptr};
         const panda::SortPlacement place{nranges > 1 ? log_n : 0u, (uint32_t)row0};
         const void *scalars_r = (const char *)cfg.scalars + row0 * 32;
         if (tabled)
@@ -977,23 +930,26 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             PANDA_TRY(panda::msm_sort_plain(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
         if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
         if (h_scalars && !last) PANDA_TRY(upload(r + 1)); // behind this range's sort in host order, beside its kernels on the device
-        if (last) PANDA_TRY(hipEventRecord(ev[3], ls));
+        if (last && wanted(3)) PANDA_TRY(hipEventRecord(ev[3], ls));
         // the first range accumulates straight into the total (zeroed: empty buckets must read as the identity); a later range into
         // its lane's own array, of which only the non-empty buckets are ever read, by the fix-up that adds them to the total
         u32 *target = r == 0 ? d_bacc : d_bacc_range[lane];
         u32 *d_parts = d_parts_l[lane], *d_lcount = d_lcount_l[lane], *d_llist = d_llist_l[lane];
-        if (r == 0) PANDA_TRY(hipMemsetAsync(d_bacc, 0, sz_bacc, ls));
+        // (no zero-fill of the bucket array: the first range's fix-up writes the identity into its empty buckets; k_accumulate empties the
+        // fix-up's queue of long buckets)
         hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
-                           NB, g.K, g.chunks);
-        if (last) PANDA_TRY(hipEventRecord(ev[4], ls));
-        PANDA_TRY(hipMemsetAsync(d_lcount, 0, sz_lcount, ls));
+                           NB, g.K, g.chunks, d_lcount);
+        if (last && wanted(4)) PANDA_TRY(hipEventRecord(ev[4], ls));
+        // 256-thread workgroups: at 2^16 buckets that is one per CU, a wave per SIMD (with 128 the dispatcher doubled them up on half
+        // the CUs and every addition took 1.6x as long: fix-up 0.225 -> 0.162 ms at 2^20 points)
+        constexpr unsigned fx_block = 256;
         if (r == 0)
-            hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + 127) / 128, lists), dim3(128), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
-                               d_llist, g.long_cap);
+            hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + fx_block - 1) / fx_block, lists), dim3(fx_block), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+                               d_llist, g.long_cap, d_tickets);
         else {
             if (lanes > 1) PANDA_TRY(hipStreamWaitEvent(ls, phase_events.fixed[r - 1], 0)); // the total is complete up to the previous range
-            hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + 127) / 128, lists), dim3(128), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
-                               d_llist, g.long_cap);
+            hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + fx_block - 1) / fx_block, lists), dim3(fx_block), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
+                               d_llist, g.long_cap, d_tickets);
         }
         hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, ls, d_parts, d_bacc, r == 0 ? 0u : 1u, NB, g.chunks, d_lcount, d_llist, g.long_cap);
         if (lanes > 1) PANDA_TRY(hipEventRecord(phase_events.fixed[r], ls));
@@ -1001,16 +957,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     }
     if (lanes > 1) PANDA_TRY(hipStreamWaitEvent(stream, phase_events.fixed[nranges - 1], 0));
     PANDA_TRY(mark(5));
-    hipLaunchKernelGGL(k_reduce_groups<Fq>, dim3((groups + 127) / 128, lists), dim3(128), 0, stream, d_bacc, d_gsum, d_gtsum, NB, groups, group);
-    if (rowcol) {
-        u32 *d_rows = d_l1, *d_cols = d_l1 + (size_t)rc_rows * PW, *d_tsum = d_l1 + (size_t)(rc_rows + rc_cols) * PW;
-        hipLaunchKernelGGL(k_rowcol_sums<Fq>, dim3(2 * rc_rows + rc_cols), dim3(256), 0, stream, d_gsum, d_gtsum, d_rows, d_cols, d_tsum, rc_rows, rc_cols);
-        hipLaunchKernelGGL(k_bit_sums2<Fq>, dim3(slots), dim3(256), 0, stream, d_rows, d_cols, d_tsum, d_slots, rc_a, rc_b, log_group);
-    } else {
-        hipLaunchKernelGGL(k_bit_sums<Fq>, dim3(nblk, slots, lists), dim3(256), 0, stream, d_gsum, d_gtsum, d_l1, groups, slots, nblk);
-        hipLaunchKernelGGL(k_bit_finish<Fq>, dim3(slots, lists), dim3(64), 0, stream, d_l1, d_slots, slots, nblk, log_group);
+    {
+        u32 *d_rows = d_l1, *d_cols = d_l1 + (size_t)lists * rc_rows * PW;
+        hipLaunchKernelGGL(k_sum_lines<Fq>, dim3(rc_rows + rc_cols * rc_csplit, lists), dim3(64), 0, stream, d_bacc, d_rows, d_cols, rc_rows, rc_cols, rc_csplit);
+        hipLaunchKernelGGL(k_weighted_finish<Fq>, dim3(slots, lists, rc_parts), dim3(64), 0, stream, d_rows, d_cols, d_slots, d_win, d_tickets, rc_a, rc_b, rc_csplit);
     }
-    hipLaunchKernelGGL(k_slot_sum<Fq>, dim3(lists), dim3(64), 0, stream, d_slots, d_win, slots);
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
 
@@ -1048,9 +999,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     PANDA_TRY(hipStreamSynchronize(stream));
 
     float ms = 0;
-    for (int i = 0; i < 6; i++) {
-        (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-        phase_ms[i] = ms;
+    for (int i = 0; i < 6; i++) { // phases whose events were not recorded in this call read 0
+        phase_ms[i] = 0;
+        if (wanted(i) && wanted(i + 1) && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) phase_ms[i] = ms;
     }
     (void)hipEventElapsedTime(&ms, ev[6], ev[7]);
     phase_ms[6] = ms;

@@ -1,5 +1,6 @@
 """Per-phase timing of the MSM with precomputed window tables against the plain registered path (development aid).
-usage: tabled_bench.py <log_n[,log_n..]> <window_bits[,..] (0 = policy)> <reduce_group[,..] (0 = policy)> [reps] [curve 0|1|2]"""
+usage: tabled_bench.py <log_n[,log_n..]> <window_bits[,..] (0 = policy)> <unused> [reps] [curve 0|1|2] [chunk[,..] (0 = policy)]
+environment: PANDA_TIMING=0|1|2 (phase timers a call records, default 2 here; the wall time is the honest figure at 0 / 1)"""
 import ctypes as C
 import os
 import sys
@@ -39,8 +40,10 @@ def main():
     groups = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0").split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     curve = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    chunks = [int(x) for x in (sys.argv[6] if len(sys.argv) > 6 else "0").split(",")]
     pt, res = (64, 96) if curve == 0 else (96, 144)
     lib = ffi.load()
+    lib.panda_msm_set_phase_timing(int(os.environ.get("PANDA_TIMING", "2")))
     fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[curve]
     gm = pgm.PandaGpuManager(0)
     names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
@@ -61,11 +64,12 @@ def main():
             tables, bits, held = C.c_uint(0), C.c_uint(0), C.c_size_t(0)
             lib.panda_msm_registered_info(db.ptr, C.byref(tables), C.byref(bits), C.byref(held))
             for g in groups:
-                lib.panda_msm_set_reduce_group(g)
-                line = run(lib, cfg, reps, names, fn)
-                same = "same-jacobian" if dr.to_host().tobytes() == ref else "different representative"
-                print(f"2^{k} tables c={bits.value:2d} W={tables.value:2d} group={g:2d} ({held.value/2**30:.1f} GiB, built in {tb:.2f}s): {line}  [{same}]", flush=True)
-            lib.panda_msm_set_reduce_group(0)
+                for ck in chunks:
+                    lib.panda_msm_set_chunk_entries(ck)
+                    line = run(lib, cfg, reps, names, fn)
+                    same = "same-jacobian" if dr.to_host().tobytes() == ref else "different representative"
+                    print(f"2^{k} tables c={bits.value:2d} W={tables.value:2d} group={g:2d} chunk={ck:3d} ({held.value/2**30:.1f} GiB, built in {tb:.2f}s): {line}  [{same}]", flush=True)
+            lib.panda_msm_set_chunk_entries(0)
             ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
         for d in (db, ds, dr):
             d.free()
