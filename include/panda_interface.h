@@ -166,6 +166,13 @@ panda_error panda_msm_combine_bn254_g2(const void *partials, unsigned count, pan
  * panda_msm_execute_*; the caller must not modify the buffer until panda_msm_unregister_bases.  curve: 0 BN254, 1 BLS12-377, 2 BLS12-381, 3 BN254 G2. */
 panda_error panda_msm_register_bases(unsigned curve, const void *d_bases, unsigned log_n, panda_stream stream);
 panda_error panda_msm_unregister_bases(const void *d_bases);
+/* Strict staleness check of a registration: recomputes the 64-bit hash of the whole wire buffer (one streaming pass, about 0.2 ms
+ * per GiB; synchronises `stream`) and compares it with the hash taken when the buffer was registered.  panda_success: unchanged;
+ * panda_error_invalid_value: not registered, or changed -- the registration has then been dropped.  (Every execute additionally
+ * compares 64 sampled rows at no cost; that catches wholesale reuse of the address, not a change confined to other rows.) */
+panda_error panda_msm_verify_registered(const void *d_bases, panda_stream stream);
+/* on != 0: every panda_msm_execute_* against registered bases runs panda_msm_verify_registered's check first */
+panda_error panda_msm_set_paranoid(unsigned on);
 /* Cached bases with precomputed window tables (the lookup-table idea the reference left as a stub, msm_host.cuh:248-265):
  * besides the converted copy the library keeps 2^lo[k] * P for every window k (W tables of 2^log_n affine rows, built once,
  * about W * 64 B per BN254 point).  Every window then shares one bucket space, which permits windows of up to 23 bits and
@@ -286,7 +293,8 @@ panda_error panda_gen_bases(unsigned curve, uint64_t seed, uint64_t first, uint6
 /* Element-wise diagnostics used by the parity tests: field id 0..5 = BN254 Fq, BN254 Fr, BLS12-377 Fq, BLS12-377 Fr, BLS12-381 Fq, BLS12-381 Fr;
  * op 0..6 = add, sub, mul, sqr, to_montgomery, from_montgomery, inverse (Montgomery in/out, 0 -> 0; field.cuh:925-972).  Device pointers. */
 panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);
-/* op 0 = Jacobian + affine (madd), 1 = Jacobian + Jacobian, 2 = double; Jacobian in/out */
+/* op 0 = Jacobian + affine (madd), 1 = Jacobian + Jacobian, 2 = double, 3 / 4 = the four-lane spellings of 1 / 2 that the MSM's
+ * fix-up and bucket-reduction trees run (csrc/curve29_quad.h); Jacobian in/out */
 panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream);
 
 const char *panda_version(void);

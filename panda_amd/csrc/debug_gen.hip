@@ -5,7 +5,7 @@
 // time with the oracle (reference counterparts: field.cuh:139-619, projective.cuh:163-314).
 // panda_gen_scalars / panda_gen_bases build the SURVEY section 8d inputs directly in HBM: 2^26 bases
 // (4 GiB) cannot sensibly be generated on the host and shipped over PCIe.
-#include "curve29.h"
+#include "curve29_quad.h"
 #include "panda_internal.h"
 
 using namespace panda29;
@@ -100,6 +100,46 @@ __global__ void __launch_bounds__(128) k_curve_op(unsigned op, u32 *__restrict__
     xyzz_to_jacobian_wire(wr, p);
 #pragma unroll
     for (int k = 0; k < 3 * L; k++) r[i * 3 * L + k] = wr[k];
+}
+
+// ops 3 / 4: the four-lane addition / doubling of curve29_quad.h (what the MSM's fix-up and bucket-reduction trees run), one QUAD per element
+template <class F>
+__device__ __noinline__ void add_quad_outlined(Xyzz<F> &acc, const Xyzz<F> &q, unsigned role)
+{
+    xyzz_add_quad(acc, q, role);
+}
+template <class F>
+__device__ __noinline__ void dbl_quad_outlined(Xyzz<F> &r, const Xyzz<F> &p, unsigned role)
+{
+    xyzz_dbl_quad(r, p, role);
+}
+
+template <class F>
+__global__ void __launch_bounds__(128) k_curve_op_quad(unsigned op, u32 *__restrict__ r, const u32 *__restrict__ a, const u32 *__restrict__ b, size_t n)
+{
+    constexpr int L = F::L;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const unsigned role = threadIdx.x & 3u;
+    if (i >= n) return; // whole quads leave together
+    u32 wa[3 * L], wb[3 * L], wr[3 * L];
+#pragma unroll
+    for (int k = 0; k < 3 * L; k++) wa[k] = a[i * 3 * L + k];
+    Xyzz<F> p, q;
+    xyzz_from_jacobian_wire(p, wa);
+    if (op == 3) {
+#pragma unroll
+        for (int k = 0; k < 3 * L; k++) wb[k] = b[i * 3 * L + k];
+        xyzz_from_jacobian_wire(q, wb);
+        add_quad_outlined(p, q, role);
+    } else {
+        dbl_quad_outlined(q, p, role);
+        p = q;
+    }
+    xyzz_to_jacobian_wire(wr, p);
+    if (role == (unsigned)(i & 3)) { // a different lane of the quad answers for each element: all four must hold the result
+#pragma unroll
+        for (int k = 0; k < 3 * L; k++) r[i * 3 * L + k] = wr[k];
+    }
 }
 
 // ---- generators: same functions of (seed, index) as oracle/gen.c
@@ -314,10 +354,16 @@ panda_error panda_debug_field_op(unsigned field_id, unsigned op, void *d_r, cons
 
 panda_error panda_debug_curve_op(unsigned curve, unsigned op, void *d_r, const void *d_a, const void *d_b, size_t n, panda_stream stream)
 {
-    if (op > 2 || curve > 3) return panda_error_invalid_value;
+    if (op > 4 || curve > 3) return panda_error_invalid_value;
     hipStream_t s = static_cast<hipStream_t>(stream.handle);
     dim3 grid((unsigned)((n + 127) / 128)), block(128);
-    if (curve == 3) hipLaunchKernelGGL(k_curve_op<Ext2<Bn254Fq>>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    if (op >= 3) {
+        dim3 qgrid((unsigned)((4 * n + 127) / 128));
+        if (curve == 3) hipLaunchKernelGGL(k_curve_op_quad<Ext2<Bn254Fq>>, qgrid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+        else if (curve == 0) hipLaunchKernelGGL(k_curve_op_quad<Bn254Fq>, qgrid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+        else if (curve == 1) hipLaunchKernelGGL(k_curve_op_quad<Bls377Fq>, qgrid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+        else hipLaunchKernelGGL(k_curve_op_quad<Bls381Fq>, qgrid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
+    } else if (curve == 3) hipLaunchKernelGGL(k_curve_op<Ext2<Bn254Fq>>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     else if (curve == 0) hipLaunchKernelGGL(k_curve_op<Bn254Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     else if (curve == 1) hipLaunchKernelGGL(k_curve_op<Bls377Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);
     else hipLaunchKernelGGL(k_curve_op<Bls381Fq>, grid, block, 0, s, op, (u32 *)d_r, (const u32 *)d_a, (const u32 *)d_b, n);

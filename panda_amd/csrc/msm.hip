@@ -99,9 +99,37 @@ hipError_t thread_helper_stream(hipStream_t *out)
     return hipSuccess;
 }
 
+namespace {
+struct Mailbox {
+    uint32_t *words = nullptr;
+    void drop()
+    {
+        if (words) (void)hipHostFree(words);
+        words = nullptr;
+    }
+    ~Mailbox() { drop(); }
+};
+thread_local Mailbox g_mailbox;
+} // namespace
+
+hipError_t thread_mailbox(uint32_t **host_words)
+{
+    if (!g_mailbox.words) {
+        // portable + mapped: one address for the host and for every device
+        hipError_t e = hipHostMalloc((void **)&g_mailbox.words, MAILBOX_WORDS * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) {
+            g_mailbox.words = nullptr;
+            return e;
+        }
+    }
+    *host_words = g_mailbox.words;
+    return hipSuccess;
+}
+
 hipError_t release_thread_arena()
 {
     g_helper.drop();
+    g_mailbox.drop();
     return thread_arena().release();
 }
 
@@ -121,9 +149,12 @@ thread_local float g_phase_ms[PANDA_MSM_PHASES] = {0};
 // Staleness: the key is the caller's raw device address, which an allocator may hand out again.  panda_free /
 // panda_free_async drop every entry whose buffer lies in the allocation being freed, and for buffers freed behind the
 // library's back (a caching allocator such as torch's) each entry keeps REG_SAMPLES rows of the wire buffer as it was
-// at registration: every execute compares them on the device and, on a mismatch, forgets the entry and runs the call
-// again from the caller's buffer.  The comparison is a SAMPLE (REG_SAMPLES rows): a recycled address whose new content differs
-// from the old one in unsampled rows only is not detected -- callers that recycle device buffers behind the library's back
+// at registration: the first kernel of every execute compares them (msm_sort.hip, check_samples) and, on a mismatch, k_accumulate
+// skips its work, the entry is forgotten and the call runs again from the caller's buffer.
+// What is and is not guaranteed: the per-call comparison is a SAMPLE (REG_SAMPLES rows) -- it catches a buffer that was freed and
+// reused wholesale, not one whose content changed in unsampled rows only.  The STRICT check is the 64-bit hash of the whole wire
+// buffer taken at registration: panda_msm_verify_registered() recomputes it on demand (one streaming pass, 0.2 ms per GiB), and
+// panda_msm_set_paranoid(1) does so in front of every execute.  Callers that recycle device buffers behind the library's back
 // should unregister first; panda_free / panda_free_async do it for them.
 struct RegisteredBases : panda::MsmRegistration {
     RegisteredBases() : panda::MsmRegistration{} {}
@@ -174,6 +205,7 @@ size_t forget_if(Pred pred)
 std::atomic<unsigned> g_window_override{0};
 std::atomic<unsigned> g_chunk{0};
 std::atomic<unsigned> g_phase_timing{1};
+std::atomic<unsigned> g_paranoid{0};
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
@@ -232,7 +264,17 @@ hipError_t msm_execute(unsigned curve, const panda_msm_configuration &cfg, const
     if (panda::extent_too_short(cfg.bases, n * kAffineBytes[curve]) || panda::extent_too_short(cfg.scalars, n * 32) ||
         panda::extent_too_short(cfg.results, kResultBytes[curve]))
         return hipErrorInvalidValue;
-    const RegisteredPtr reg = lookup_registered(cfg.bases, cfg.log_scalars_count, curve); // held for the whole call
+    RegisteredPtr reg = lookup_registered(cfg.bases, cfg.log_scalars_count, curve); // held for the whole call
+    if (reg && g_paranoid.load(std::memory_order_relaxed)) { // strict mode: the whole buffer must still hash to what was registered
+        uint64_t now = 0;
+        PANDA_TRY(panda::msm_hash_wire(cfg.bases, n * kAffineBytes[curve], static_cast<hipStream_t>(cfg.stream.handle), &now));
+        if (now != reg->hash) {
+            fprintf(stderr, "[panda-hip] registered bases at %p changed since registration (hash): registration dropped, converting per call\n", cfg.bases);
+            const RegisteredBases *gone = reg.get();
+            forget_if([gone](const RegisteredBases &r) { return &r == gone; });
+            reg.reset();
+        }
+    }
     bool stale = false;
     hipError_t e = msm_execute_on(curve, cfg, reg.get(), &stale, pipe);
     if (e == hipSuccess && stale) {
@@ -284,7 +326,52 @@ hipError_t register_bases(unsigned curve, const void *d_bases, unsigned log_n, b
 
 } // namespace
 
+namespace {
+
+__device__ __forceinline__ u64 mix64(u64 x)
+{
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// sum over the 16-byte units of the buffer of a position-dependent mix of their content: order-independent, so every workgroup adds
+// its share with one atomic; one streaming pass (0.2 ms per GiB)
+__global__ void __launch_bounds__(256) k_hash_wire(const uint4 *__restrict__ buf, u64 units, unsigned long long *__restrict__ out)
+{
+    __shared__ u64 partial[4];
+    u64 h = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < units; i += (u64)gridDim.x * 256) {
+        const uint4 v = buf[i];
+        const u64 a = ((u64)v.y << 32) | v.x, b = ((u64)v.w << 32) | v.z;
+        h += mix64(a + 0x9E3779B97F4A7C15ull * (2 * i + 1)) ^ mix64(b ^ (0xD1342543DE82EF95ull * (2 * i + 2)));
+    }
+    for (int d = 32; d > 0; d >>= 1) h += __shfl_down(h, d, 64);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(partial[0] + partial[1] + partial[2] + partial[3]));
+}
+
+} // namespace
+
 namespace panda {
+
+hipError_t msm_hash_wire(const void *d_buf, size_t bytes, hipStream_t s, uint64_t *hash)
+{
+    uint32_t *mail = nullptr;
+    PANDA_TRY(thread_mailbox(&mail));
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(mail + 32); // pinned host memory the kernel adds into directly
+    *h = 0;
+    const u64 units = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<u64>((units + 255) / 256, 4096);
+    if (units) hipLaunchKernelGGL(k_hash_wire, dim3(blocks), dim3(256), 0, s, (const uint4 *)d_buf, units, h);
+    PANDA_TRY(hipGetLastError());
+    PANDA_TRY(hipStreamSynchronize(s));
+    *hash = *h;
+    return hipSuccess;
+}
 
 // panda_free / panda_free_async: no registration may outlive the buffer it was made for
 void registry_forget_allocation(const void *ptr)
@@ -334,6 +421,30 @@ panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, uns
             return panda_success;
         }
     return panda_error_invalid_value;
+}
+
+panda_error panda_msm_verify_registered(const void *d_bases, panda_stream stream)
+{
+    RegisteredPtr reg;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        for (const auto &r : g_registry)
+            if (r->wire == d_bases) reg = r;
+    }
+    if (!reg) return panda_error_invalid_value;
+    uint64_t now = 0;
+    const hipError_t e = panda::msm_hash_wire(d_bases, ((size_t)1 << reg->log_n) * kAffineBytes[reg->curve], static_cast<hipStream_t>(stream.handle), &now);
+    if (e != hipSuccess) return static_cast<panda_error>(e);
+    if (now == reg->hash) return panda_success;
+    const RegisteredBases *gone = reg.get();
+    forget_if([gone](const RegisteredBases &r) { return &r == gone; });
+    return panda_error_invalid_value; // the buffer no longer holds what was registered: the registration is gone
+}
+
+panda_error panda_msm_set_paranoid(unsigned on)
+{
+    g_paranoid.store(on ? 1u : 0u, std::memory_order_relaxed);
+    return panda_success;
 }
 
 panda_error panda_msm_unregister_bases(const void *d_bases)

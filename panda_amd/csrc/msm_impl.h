@@ -47,8 +47,10 @@ struct MsmRegistration {
     WindowPlan plan;
     size_t bytes;            // converted rows / tables (what panda_msm_registered_info reports)
     const uint32_t *samples; // REG_SAMPLES rows of the wire buffer as registered, kept behind the tables (stale-address check)
+    uint64_t hash;           // of the whole wire buffer as registered (msm_hash_wire): the strict check, on demand
 };
-constexpr unsigned REG_SAMPLES = 64;
+// order-independent 64-bit hash of `bytes` (a multiple of 16) of device memory, on `s`; synchronises
+hipError_t msm_hash_wire(const void *d_buf, size_t bytes, hipStream_t s, uint64_t *hash);
 
 struct MsmTuning {
     unsigned window_bits;  // plain-mode window width (already resolved by the policy)
@@ -266,26 +268,13 @@ __device__ __forceinline__ void xyzz_dbl_q(Xyzz<F> &r, const Xyzz<F> &p, unsigne
         xyzz_dbl_quad(r, p, role);
 }
 
-// Rows of the caller's wire buffer remembered at registration and compared on every execute (msm.hip, "Staleness").
-// Sample t is row 0, row n-1, or a fixed pseudo-random row; block = REG_SAMPLES x 16 threads, lane l owns words l, l+16, ...
-__device__ __forceinline__ u64 sample_row(unsigned t, u64 n) { return t == 0 ? 0 : (t == 1 ? n - 1 : (((u64)t * 0x9E3779B97F4A7C15ull) >> 20) & (n - 1)); }
-
+// Rows of the caller's wire buffer remembered at registration; the digits kernel of every execute compares them (msm_sort.hip,
+// check_samples; msm.hip, "Staleness").  Block = REG_SAMPLES x 16 threads, lane l owns words l, l+16, ...
 __global__ void __launch_bounds__(panda::REG_SAMPLES * 16) k_take_samples(const u32 *__restrict__ wire, u32 *__restrict__ samples, u64 n, unsigned row_words)
 {
     const unsigned t = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const u64 row = sample_row(t, n);
+    const u64 row = panda::sample_row(t, n);
     for (unsigned k = l; k < row_words; k += 16) samples[t * row_words + k] = wire[row * row_words + k];
-}
-
-__global__ void __launch_bounds__(panda::REG_SAMPLES * 16) k_check_samples(const u32 *__restrict__ wire, const u32 *__restrict__ samples, u64 n, unsigned row_words,
-                                                                          u32 *__restrict__ flag)
-{
-    const unsigned t = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const u64 row = sample_row(t, n);
-    int differs = 0;
-    for (unsigned k = l; k < row_words; k += 16) differs |= samples[t * row_words + k] != wire[row * row_words + k];
-    differs = __syncthreads_or(differs);
-    if (threadIdx.x == 0) *flag = differs ? 1u : 0u;
 }
 
 // first index in off[0..NB] whose value exceeds pos, minus one: the bucket that owns sorted position pos
@@ -344,13 +333,16 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 template <class F>
 __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
-                                                    unsigned chunks, u32 *__restrict__ long_count)
+                                                    unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunks) return;
     if (t == 0) long_count[w] = 0; // the fix-up's queue of long buckets starts empty (it runs behind this kernel on the same stream)
+    // the registered buffer no longer holds what was registered (the digits kernel of this range found out): the call will be repeated
+    // from the caller's buffer, and nine tenths of the work it would waste are in this kernel
+    if (stale && *stale) return;
     const u32 *ow = off + (u64)w * (NB + 1);
     const u32 nw = ow[NB];
     const u32 start = t * K;
@@ -624,10 +616,12 @@ __global__ void __launch_bounds__(64) k_sum_lines(const u32 *__restrict__ bucket
 // times;  slot 1+a+j (j < b): the column (segment) sums with bit j of lo set, doubled j times (rows = 2^a, cols = 2^b).  A slot's
 // entries are shared out over `parts` workgroups, each of which doubles its own partial sum (2^k (x + y) = 2^k x + 2^k y: the doublings
 // of the parts run side by side).  The workgroup that finishes last (tickets[list]) adds the list's slots * parts partial sums up
-// into win[list].
+// into win[list] -- as an XYZZ point (emit = 0: the host still has a Horner step to do over the lists), or, for a single list whose
+// sum IS the result, in the wire format of the C ABI: Jacobian X || Y || Z (emit = 1) or homogeneous (emit = 2).  `win` may be device
+// memory or pinned host memory.
 template <class F>
 __global__ void __launch_bounds__(64) k_weighted_finish(const u32 *__restrict__ inR, const u32 *__restrict__ inC, u32 *slot_out, u32 *__restrict__ win, u32 *tickets,
-                                                        unsigned a, unsigned b, unsigned csplit)
+                                                        unsigned a, unsigned b, unsigned csplit, unsigned emit)
 {
     constexpr int PW = 4 * F::N;
     __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
@@ -683,7 +677,19 @@ __global__ void __launch_bounds__(64) k_weighted_finish(const u32 *__restrict__ 
         xyzz_add_k(acc, q);
     }
     wave_reduce<F>(acc, lds, lane);
-    if (lane == 0) store_xyzz<F>(win + (u64)list * PW, acc);
+    if (lane == 0) {
+        if (emit == 0)
+            store_xyzz<F>(win + (u64)list * PW, acc);
+        else {
+            u32 out[3 * F::L];
+            if (emit == 2)
+                xyzz_to_homogeneous_wire(out, acc);
+            else
+                xyzz_to_jacobian_wire(out, acc);
+#pragma unroll
+            for (int k = 0; k < 3 * F::L; k++) win[k] = out[k];
+        }
+    }
 }
 
 // Precomputed window tables for cached bases (the reference left the idea as a stub,
@@ -813,7 +819,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     }
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
     const size_t sz_l1 = panda::align256((size_t)lists * (rc_rows + rc_cols * rc_csplit) * PW * 4);
-    const size_t sz_win = panda::align256((size_t)lists * PW * 4 + 4); // + the stale-registration flag, fetched with the window sums
+    const size_t sz_win = 256; // the stale-registration flag (device copy: k_accumulate reads it)
     const size_t sz_tickets = panda::align256((size_t)lists * 4);
     const size_t sz_slots = panda::align256((size_t)lists * slots * rc_parts * PW * 4);
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
@@ -834,10 +840,32 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         if (!d_bacc_range[l] || !d_parts_l[l] || !d_lcount_l[l] || !d_llist_l[l]) return hipErrorOutOfMemory;
     }
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
-    u32 *d_win = (u32 *)arena.take(sz_win);
+    u32 *d_stale = (u32 *)arena.take(sz_win);
     u32 *d_slots = (u32 *)arena.take(sz_slots);
     u32 *d_tickets = (u32 *)arena.take(sz_tickets);
-    if (!d_bases || !d_bacc || !d_l1 || !d_win || !d_slots || !d_tickets) return hipErrorOutOfMemory;
+    if (!d_bases || !d_bacc || !d_l1 || !d_stale || !d_slots || !d_tickets) return hipErrorOutOfMemory;
+    // What the call hands back to this host thread travels through pinned host memory the kernels write into directly: word 0 is set
+    // by the digits kernel when the registered buffer has changed, the window sums (or, with tables, the finished result) land behind it.
+    u32 *mail = nullptr;
+    PANDA_TRY(panda::thread_mailbox(&mail));
+    if (64 + (size_t)lists * PW > panda::MAILBOX_WORDS) return hipErrorInvalidValue;
+    volatile u32 *h_flag = mail;
+    u32 *h_win = mail + 64;
+    *h_flag = 0;
+    const panda::SampleCheck sample_check{registered ? (const u32 *)cfg.bases : nullptr, registered ? registration->samples : nullptr, n, 2u * LQ, d_stale, mail};
+    // With tables the single list's sum is the result, and the last kernel writes it in wire form where the caller wants it -- if that
+    // is memory a kernel can address (device memory of this device, pinned or registered host memory; unit.rs:32-47, msm_test.cu:53,125);
+    // anything else gets it through the mailbox and a copy.
+    u32 *res_dev = nullptr;
+    if (tabled) {
+        hipPointerAttribute_t at{};
+        int dev = -1;
+        if (hipPointerGetAttributes(&at, cfg.results) == hipSuccess && hipGetDevice(&dev) == hipSuccess && at.devicePointer &&
+            ((at.type == hipMemoryTypeDevice && at.device == dev) || at.type == hipMemoryTypeHost))
+            res_dev = (u32 *)at.devicePointer;
+        else
+            (void)hipGetLastError();
+    }
     const size_t sort_mark[2] = {arena.used, arena.used + panda::align256(sz_sort) + 512}; // a lane's sorts carve their scratch from its mark again
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
@@ -899,10 +927,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
 
     PANDA_TRY(mark(0));
     if (h_scalars) PANDA_TRY(upload(0));
-    u32 *d_stale = d_win + (size_t)lists * PW;
-    if (registered)
-        hipLaunchKernelGGL(k_check_samples, dim3(1), dim3(panda::REG_SAMPLES * 16), 0, stream, (const u32 *)cfg.bases, registration->samples, n, 2u * LQ, d_stale);
-    else
+    if (!registered)
         hipLaunchKernelGGL(k_convert_bases<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)cfg.bases, const_cast<u32 *>(d_bases), n);
     if (lanes > 1) { // the helper lane starts after everything the caller's stream held before this call
         phase_events.fixed.assign(nranges, nullptr);
@@ -925,9 +950,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         const panda::SortPlacement place{nranges > 1 ? log_n : 0u, (uint32_t)row0};
         const void *scalars_r = (const char *)cfg.scalars + row0 * 32;
         if (tabled)
-            PANDA_TRY(panda::msm_sort_tabled(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+            PANDA_TRY(panda::msm_sort_tabled(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place, sample_check));
         else
-            PANDA_TRY(panda::msm_sort_plain(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place));
+            PANDA_TRY(panda::msm_sort_plain(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place, sample_check));
         if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
         if (h_scalars && !last) PANDA_TRY(upload(r + 1)); // behind this range's sort in host order, beside its kernels on the device
         if (last && wanted(3)) PANDA_TRY(hipEventRecord(ev[3], ls));
@@ -938,7 +963,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         // (no zero-fill of the bucket array: the first range's fix-up writes the identity into its empty buckets; k_accumulate empties the
         // fix-up's queue of long buckets)
         hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
-                           NB, g.K, g.chunks, d_lcount);
+                           NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr);
         if (last && wanted(4)) PANDA_TRY(hipEventRecord(ev[4], ls));
         // 256-thread workgroups: at 2^16 buckets that is one per CU, a wave per SIMD (with 128 the dispatcher doubled them up on half
         // the CUs and every addition took 1.6x as long: fix-up 0.225 -> 0.162 ms at 2^20 points)
@@ -960,43 +985,45 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     {
         u32 *d_rows = d_l1, *d_cols = d_l1 + (size_t)lists * rc_rows * PW;
         hipLaunchKernelGGL(k_sum_lines<Fq>, dim3(rc_rows + rc_cols * rc_csplit, lists), dim3(64), 0, stream, d_bacc, d_rows, d_cols, rc_rows, rc_cols, rc_csplit);
-        hipLaunchKernelGGL(k_weighted_finish<Fq>, dim3(slots, lists, rc_parts), dim3(64), 0, stream, d_rows, d_cols, d_slots, d_win, d_tickets, rc_a, rc_b, rc_csplit);
+        const unsigned emit = tabled ? (cfg.msm_result_coordinate_type == PROJECTIVE ? 2u : 1u) : 0u;
+        hipLaunchKernelGGL(k_weighted_finish<Fq>, dim3(slots, lists, rc_parts), dim3(64), 0, stream, d_rows, d_cols, d_slots, res_dev ? res_dev : h_win, d_tickets, rc_a,
+                           rc_b, rc_csplit, emit);
     }
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
-
-    std::vector<u32> h_win((size_t)lists * PW + 1, 0u);
-    PANDA_TRY(hipMemcpyAsync(h_win.data(), d_win, ((size_t)lists * PW + (registered ? 1 : 0)) * 4, hipMemcpyDeviceToHost, stream));
+    if (res_dev) PANDA_TRY(mark(7)); // nothing follows on the device
     PANDA_TRY(hipStreamSynchronize(stream));
-    if (registered && h_win[(size_t)lists * PW] != 0) { // the caller's buffer is not what was registered: the sums above mean nothing
+    if (*h_flag != 0) { // the caller's buffer is not what was registered: the sums mean nothing (and k_accumulate skipped its work)
         if (stale) *stale = true;
         return hipSuccess;
     }
-
-    std::vector<Xyzz<Fq>> windows(lists);
-    for (unsigned w = 0; w < lists; w++) {
-        const u32 *src = h_win.data() + (size_t)w * PW;
-        for (int i = 0; i < Fq::N; i++) {
-            windows[w].X.l[i] = src[i];
-            windows[w].Y.l[i] = src[Fq::N + i];
-            windows[w].ZZ.l[i] = src[2 * Fq::N + i];
-            windows[w].ZZZ.l[i] = src[3 * Fq::N + i];
+    if (!res_dev) {
+        if (tabled) // the result itself came through the mailbox
+            PANDA_TRY(hipMemcpyAsync(cfg.results, h_win, 3 * LQ * 4, hipMemcpyDefault, stream));
+        else {
+            std::vector<Xyzz<Fq>> windows(lists);
+            for (unsigned w = 0; w < lists; w++) {
+                const u32 *src = h_win + (size_t)w * PW;
+                for (int i = 0; i < Fq::N; i++) {
+                    windows[w].X.l[i] = src[i];
+                    windows[w].Y.l[i] = src[Fq::N + i];
+                    windows[w].ZZ.l[i] = src[2 * Fq::N + i];
+                    windows[w].ZZZ.l[i] = src[3 * Fq::N + i];
+                }
+            }
+            Xyzz<Fq> result;
+            host_horner(result, windows, plan);
+            u32 out[3 * LQ];
+            if (cfg.msm_result_coordinate_type == PROJECTIVE)
+                xyzz_to_homogeneous_wire(out, result);
+            else
+                xyzz_to_jacobian_wire(out, result);
+            // results may be a device pointer (unit.rs:32-47) or pinned host memory (msm_test.cu:53,125)
+            PANDA_TRY(hipMemcpyAsync(cfg.results, out, sizeof(out), hipMemcpyDefault, stream));
         }
+        PANDA_TRY(mark(7));
+        PANDA_TRY(hipStreamSynchronize(stream));
     }
-    Xyzz<Fq> result;
-    if (tabled)
-        result = windows[0]; // the tables already carry the 2^lo[k] factors
-    else
-        host_horner(result, windows, plan);
-    u32 out[3 * LQ];
-    if (cfg.msm_result_coordinate_type == PROJECTIVE)
-        xyzz_to_homogeneous_wire(out, result);
-    else
-        xyzz_to_jacobian_wire(out, result);
-    // results may be a device pointer (unit.rs:32-47) or pinned host memory (msm_test.cu:53,125)
-    PANDA_TRY(hipMemcpyAsync(cfg.results, out, sizeof(out), hipMemcpyDefault, stream));
-    PANDA_TRY(mark(7));
-    PANDA_TRY(hipStreamSynchronize(stream));
 
     float ms = 0;
     for (int i = 0; i < 6; i++) { // phases whose events were not recorded in this call read 0
@@ -1028,7 +1055,7 @@ hipError_t build_registration(panda::MsmRegistration &r, hipStream_t s)
         hipLaunchKernelGGL(k_table_step<Fq>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, t0 + (size_t)(k - 1) * n * 2 * Fq::L,
                            t0 + (size_t)k * n * 2 * Fq::L, n, (unsigned)r.plan.width[k - 1]);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = panda::msm_hash_wire(r.wire, (size_t)n * row, s, &r.hash); // synchronises
     if (e != hipSuccess) {
         (void)hipFree(r.converted);
         r.converted = nullptr;

@@ -33,6 +33,19 @@ struct SortPlacement {
     uint32_t row0;
 };
 
+// Stale-registration check carried by the first kernel of the sort (msm.hip, "Staleness"): REG_SAMPLES rows of the caller's wire
+// buffer are compared with the copies taken at registration; *flag_dev = 0 / 1 either way, *flag_host = 1 on a mismatch.
+// wire == nullptr: nothing to check.
+constexpr unsigned REG_SAMPLES = 64;
+struct SampleCheck {
+    const uint32_t *wire, *samples;
+    uint64_t n;
+    unsigned row_words;
+    uint32_t *flag_dev, *flag_host;
+};
+// sample t is row 0, row n-1, or a fixed pseudo-random row
+static __host__ __device__ inline uint64_t sample_row(unsigned t, uint64_t n) { return t == 0 ? 0 : (t == 1 ? n - 1 : (((uint64_t)t * 0x9E3779B97F4A7C15ull) >> 20) & (n - 1)); }
+
 // optional events recorded on `stream` between the phases (may be null)
 struct SortEvents {
     hipEvent_t digits_done, partition_done;
@@ -41,13 +54,13 @@ struct SortEvents {
 // Plain mode: W independent lists (one per window), entries index the caller's n bases.
 size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                          SortResult *out, SortPlacement place = SortPlacement{0, 0});
+                          SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{});
 
 // Tabled mode: one list over all windows; entry index = k * n + i names row i of table k (= 2^lo[k] * base i), so
 // every window falls into the same 2^(c-1) buckets and the window sums need no Horner step.
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan);
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out, SortPlacement place = SortPlacement{0, 0});
+                           SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{});
 
 } // namespace panda

@@ -55,14 +55,30 @@ __device__ __forceinline__ void load_words(u32 *dst, const u32 *src)
     }
 }
 
+// workgroup 0 of the digits kernel (256 threads, four per sampled row); every thread of the workgroup must call it
+__device__ __forceinline__ void check_samples(const panda::SampleCheck &sc)
+{
+    int differs = 0;
+    for (unsigned t = threadIdx.x >> 2; t < panda::REG_SAMPLES; t += blockDim.x >> 2) {
+        const u64 row = panda::sample_row(t, sc.n);
+        for (unsigned k = threadIdx.x & 3u; k < sc.row_words; k += 4) differs |= sc.samples[t * sc.row_words + k] != sc.wire[row * sc.row_words + k];
+    }
+    differs = __syncthreads_or(differs);
+    if (threadIdx.x == 0) {
+        *sc.flag_dev = differs ? 1u : 0u;
+        if (differs) *sc.flag_host = 1u;
+    }
+}
+
 // scalar (Montgomery wire form) -> W signed digits.  code = (neg << SIGN) | (|d| - 1), ZERO for d = 0.
 // Replaces init_handle_scalars_kernel + the slice extraction of calc_lens/fill_arrs (msm_cuda.cuh:148-205,232-282);
 // the scalars are only read.
 template <class Fr, class Code>
-__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, Code *__restrict__ dig, u64 n, panda::WindowPlan plan)
+__global__ void __launch_bounds__(256) k_digits(const u32 *__restrict__ scalars, Code *__restrict__ dig, u64 n, panda::WindowPlan plan, panda::SampleCheck sc)
 {
     typedef CodeTraits<Code> CT;
     constexpr int L = Fr::L;
+    if (blockIdx.x == 0 && sc.wire) check_samples(sc);
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[L], s[L + 1];
@@ -102,11 +118,12 @@ struct DigitsHistGeom {
 
 template <class Fr, class Code>
 __global__ void __launch_bounds__(256) k_digits_hist(const u32 *__restrict__ scalars, Code *__restrict__ dig, u32 *__restrict__ tile_hist, u64 n,
-                                                     panda::WindowPlan plan, DigitsHistGeom g)
+                                                     panda::WindowPlan plan, DigitsHistGeom g, panda::SampleCheck sc)
 {
     typedef CodeTraits<Code> CT;
     constexpr int L = Fr::L;
     extern __shared__ u32 hist[]; // [W][H]
+    if (blockIdx.x == 0 && sc.wire) check_samples(sc);
     const unsigned tile = blockIdx.x, tid = threadIdx.x;
     const unsigned WH = plan.W * g.H;
     for (unsigned i = tid; i < WH; i += 256) hist[i] = 0;
@@ -846,40 +863,41 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
 
 
 template <class Fr, class Code>
-void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan)
+void launch_digits(hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan, const panda::SampleCheck &sc)
 {
-    hipLaunchKernelGGL((k_digits<Fr, Code>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)scalars, dig, n, plan);
+    hipLaunchKernelGGL((k_digits<Fr, Code>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const u32 *)scalars, dig, n, plan, sc);
 }
 
 template <class Code>
-void launch_digits_for(unsigned fr, hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan)
+void launch_digits_for(unsigned fr, hipStream_t stream, const void *scalars, Code *dig, u64 n, const panda::WindowPlan &plan, const panda::SampleCheck &sc)
 {
     switch (fr) {
-    case 0: launch_digits<Bn254Fr, Code>(stream, scalars, dig, n, plan); break;
-    case 1: launch_digits<Bls377Fr, Code>(stream, scalars, dig, n, plan); break;
-    default: launch_digits<Bls381Fr, Code>(stream, scalars, dig, n, plan); break;
+    case 0: launch_digits<Bn254Fr, Code>(stream, scalars, dig, n, plan, sc); break;
+    case 1: launch_digits<Bls377Fr, Code>(stream, scalars, dig, n, plan, sc); break;
+    default: launch_digits<Bls381Fr, Code>(stream, scalars, dig, n, plan, sc); break;
     }
 }
 
 // digits + level-1 histogram; returns false if the fused kernel does not apply (the caller then runs k_digits + k_part_hist)
 template <class Fr, class Code>
-bool launch_digits_hist(hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan, const SortGeom &g)
+bool launch_digits_hist(hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan, const SortGeom &g,
+                        const panda::SampleCheck &sc)
 {
     const size_t lds = (size_t)plan.W * g.H * 4;
     if (g.tiles < 512 || lds > 48 * 1024) return false;
     const DigitsHistGeom dg{g.lo_bits, g.H, g.tiles};
-    hipLaunchKernelGGL((k_digits_hist<Fr, Code>), dim3(g.tiles), dim3(256), lds, stream, (const u32 *)scalars, dig, tile_hist, n, plan, dg);
+    hipLaunchKernelGGL((k_digits_hist<Fr, Code>), dim3(g.tiles), dim3(256), lds, stream, (const u32 *)scalars, dig, tile_hist, n, plan, dg, sc);
     return true;
 }
 
 template <class Code>
 bool launch_digits_hist_for(unsigned fr, hipStream_t stream, const void *scalars, Code *dig, u32 *tile_hist, u64 n, const panda::WindowPlan &plan,
-                            const SortGeom &g)
+                            const SortGeom &g, const panda::SampleCheck &sc)
 {
     switch (fr) {
-    case 0: return launch_digits_hist<Bn254Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
-    case 1: return launch_digits_hist<Bls377Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
-    default: return launch_digits_hist<Bls381Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g);
+    case 0: return launch_digits_hist<Bn254Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g, sc);
+    case 1: return launch_digits_hist<Bls377Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g, sc);
+    default: return launch_digits_hist<Bls381Fr, Code>(stream, scalars, dig, tile_hist, n, plan, g, sc);
     }
 }
 
@@ -932,7 +950,7 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
 }
 
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                          SortResult *out, SortPlacement place)
+                          SortResult *out, SortPlacement place, SampleCheck check)
 {
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
@@ -953,8 +971,8 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     u32 *d_sorted = (u32 *)arena.take(n * W * 4);
     if (!d_dig || !d_thist || !d_tpref || !d_poff || !d_ptot || !d_p1 || !d_off || !d_sorted) return hipErrorOutOfMemory;
 
-    const bool fused = launch_digits_hist_for<uint16_t>(fr, stream, scalars, d_dig, d_thist, n, plan, geom);
-    if (!fused) launch_digits_for<uint16_t>(fr, stream, scalars, d_dig, n, plan);
+    const bool fused = launch_digits_hist_for<uint16_t>(fr, stream, scalars, d_dig, d_thist, n, plan, geom, check);
+    if (!fused) launch_digits_for<uint16_t>(fr, stream, scalars, d_dig, n, plan, check);
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     if (!fused) hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(geom.tiles, W), dim3(256), 0, stream, d_dig, d_thist, geom);
     hipLaunchKernelGGL(k_part_scan_cols, dim3((geom.H + 15) / 16, W), dim3(1024), 0, stream, d_thist, d_tpref, d_ptot, geom);
@@ -995,7 +1013,7 @@ size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
 }
 
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out, SortPlacement place)
+                           SortResult *out, SortPlacement place, SampleCheck check)
 {
     if (!msm_sort_tabled_supported(log_n, plan)) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
@@ -1037,8 +1055,8 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
         !d_off || !d_sorted)
         return hipErrorOutOfMemory;
 
-    const bool fused = launch_digits_hist_for<u32>(fr, stream, scalars, d_dig, d_thist1, n, plan, g1);
-    if (!fused) launch_digits_for<u32>(fr, stream, scalars, d_dig, n, plan);
+    const bool fused = launch_digits_hist_for<u32>(fr, stream, scalars, d_dig, d_thist1, n, plan, g1, check);
+    if (!fused) launch_digits_for<u32>(fr, stream, scalars, d_dig, n, plan, check);
     if (ev.digits_done) PANDA_TRY(hipEventRecord(ev.digits_done, stream));
     // level 1, per window
     if (!fused) hipLaunchKernelGGL(k_part_hist<u32>, dim3(g1.tiles, W), dim3(256), 0, stream, d_dig, d_thist1, g1);

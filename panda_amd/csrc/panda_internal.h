@@ -8,13 +8,14 @@
 #include "../../include/panda_interface.h"
 
 // Early-return on a failing runtime call, printing where (the reference's HANDLE_RESULT_CUDA,
-// src/cuda/core/common/common.cuh:14-22, does the same on stdout).
+// src/cuda/core/common/common.cuh:14-22, does the same on stdout; here it goes to stderr: callers such as bench.py
+// speak JSON lines on stdout).
 #define PANDA_TRY(expr)                                                                                        \
     do {                                                                                                       \
         hipError_t panda_err__ = (expr);                                                                       \
         if (panda_err__ != hipSuccess) {                                                                       \
-            printf("[panda-hip] error %d (%s) at %s:%d: %s\n", (int)panda_err__, hipGetErrorName(panda_err__), \
-                   __FILE__, __LINE__, #expr);                                                                 \
+            fprintf(stderr, "[panda-hip] error %d (%s) at %s:%d: %s\n", (int)panda_err__,                      \
+                    hipGetErrorName(panda_err__), __FILE__, __LINE__, #expr);                                  \
             return panda_err__;                                                                                \
         }                                                                                                      \
     } while (0)
@@ -52,6 +53,12 @@ hipError_t release_thread_arena();
 // a second stream of this host thread on the current device (created on first use, destroyed with the arena): the other lane of an
 // MSM that runs in point ranges
 hipError_t thread_helper_stream(hipStream_t *out);
+
+// Pinned host memory of this host thread that kernels write into directly (the stale-registration flag, the window sums or the
+// finished result of an MSM): what a call hands back to its host side arrives with the kernel that produced it, without a
+// device-to-host copy of its own behind it (each cost ~10 us of a 1.5 ms call).  MAILBOX_WORDS u32, allocated on first use.
+constexpr size_t MAILBOX_WORDS = 16384;
+hipError_t thread_mailbox(uint32_t **host_words);
 
 // drops every cached-bases registration whose buffer lies in the allocation `ptr` belongs to (msm.hip); called by
 // panda_free / panda_free_async before the memory goes back to the allocator

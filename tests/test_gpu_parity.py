@@ -87,7 +87,10 @@ def test_curve_ops_elementwise(cid):
     negj[:, lc:2 * lc] = neg[:, lc:] if False else po.f_vec(po.FQ_OF[cid], po.OP_SUB, np.zeros_like(jac[:, lc:2 * lc]), jac[:, lc:2 * lc])
     for A, B in ((jac, jac[::-1].copy()), (jac, jac), (jac, negj), (ident, jac), (jac, ident)):
         same(run(1, A, B), po.curve_vec(cid, po.COP_ADD, A, B))
+        same(run(3, A, B), po.curve_vec(cid, po.COP_ADD, A, B))  # four lanes per addition (curve29_quad.h: the MSM's reduction trees)
     same(run(2, jac, jac), po.curve_vec(cid, po.COP_DBL, jac))
+    same(run(4, jac, jac), po.curve_vec(cid, po.COP_DBL, jac))
+    same(run(4, ident, ident), po.curve_vec(cid, po.COP_DBL, ident))
 
 
 @pytest.mark.parametrize("cid", [0, 1, 2])
@@ -808,6 +811,29 @@ def test_msm_registration_does_not_outlive_its_buffer(gm, tabled):
     ffi.check(lib.panda_memcpy(db2.ptr, C.c_void_p(old.ctypes.data), old.nbytes), "memcpy")
     assert (run(db2) == po.expected_from_linearity(0, 9970, scalars)).all()
     assert lib.panda_msm_registered_info(db2.ptr, None, None, None) != 0  # the stale entry was dropped
+    # (3) ONE row changed, outside the rows sampled at registration: the per-call sample cannot see it (documented), the strict
+    # check -- the hash of the whole buffer -- does: on demand, and in front of every execute in paranoid mode
+    sampled = {0, n - 1} | {((t * 0x9E3779B97F4A7C15) >> 20) & (n - 1) for t in range(2, 64)}
+    row = next(i for i in range(1, n) if i not in sampled)
+    mixed = old.copy()
+    mixed.reshape(n, -1)[row] = new.reshape(n, -1)[row]
+    mixed_want = po.msm_affine(0, mixed.reshape(-1), scalars, window_bits=10)
+    ffi.check(reg(0, db2.ptr, k, *args), "register")  # db2 holds `old`
+    assert lib.panda_msm_verify_registered(db2.ptr, gm.exec_stream.raw) == 0
+    one = np.ascontiguousarray(new.reshape(n, -1)[row])
+    ffi.check(lib.panda_memcpy(C.c_void_p(db2.ptr.value + row * one.nbytes), C.c_void_p(one.ctypes.data), one.nbytes), "memcpy")
+    assert lib.panda_msm_verify_registered(db2.ptr, gm.exec_stream.raw) != 0  # detected ...
+    assert lib.panda_msm_registered_info(db2.ptr, None, None, None) != 0  # ... and dropped
+    assert (run(db2) == mixed_want).all()
+    ffi.check(lib.panda_memcpy(db2.ptr, C.c_void_p(old.ctypes.data), old.nbytes), "memcpy")
+    ffi.check(reg(0, db2.ptr, k, *args), "register")
+    ffi.check(lib.panda_memcpy(C.c_void_p(db2.ptr.value + row * one.nbytes), C.c_void_p(one.ctypes.data), one.nbytes), "memcpy")
+    ffi.check(lib.panda_msm_set_paranoid(1), "paranoid")
+    try:
+        assert (run(db2) == mixed_want).all()
+    finally:
+        lib.panda_msm_set_paranoid(0)
+    assert lib.panda_msm_registered_info(db2.ptr, None, None, None) != 0
     for d in (db2, ds, dr):
         d.free()
 
