@@ -210,28 +210,44 @@ std::atomic<unsigned> g_paranoid{0};
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
 
-// window width policy (replaces get_window_bits_count, msm_cuda.cuh:21-45)
-unsigned pick_window_bits(unsigned log_n)
+// A bucket costs about as much as five mixed additions by the time it has been through the fix-up, the row / column sums and the
+// finishing kernel (fitted to 2^20 ... 2^24 points with and without tables: profiles/r04_window_sweeps.txt).
+constexpr double kBucketCost = 5.0;
+
+// window width policy of the plain path (replaces get_window_bits_count, msm_cuda.cuh:21-45): every window has its own 2^(c-1) buckets
+// (signed digits), so minimise  W(c) * (n * s(c) + 4.5 * 2^(c-1))  over the widths the sort supports, s = 1.04 for the windows wider
+// than 16 bits (their three-level sort moves every entry once more): 16 bits up to 2^22 points, 17 at 2^23, 20 from 2^24 on
+// (measured: 2^24 21.4 -> 19.7 ms, 2^23 11.09 -> 10.8; rounds 1-3 stopped at 16 bits: two-byte digit codes and a two-level sort)
+unsigned pick_window_bits(unsigned fr, unsigned log_n)
 {
-    const unsigned forced = g_window_override.load(std::memory_order_relaxed);
-    if (forced) return std::min(std::max(forced, 4u), 16u);
-    int c = (int)log_n - 4;
-    return (unsigned)std::min(std::max(c, 4), 16);
+    if (const unsigned forced = g_window_override.load(std::memory_order_relaxed)) {
+        const unsigned c = std::min(std::max(forced, 4u), 20u);
+        return panda::msm_sort_plain_supported(log_n, panda::make_safe_window_plan(fr, c)) ? c : std::min(c, 16u);
+    }
+    unsigned best = 0;
+    double best_cost = 0;
+    for (unsigned c = 4; c <= 20; c++) {
+        const panda::WindowPlan plan = panda::make_safe_window_plan(fr, c);
+        if (plan.width[0] != c || !panda::msm_sort_plain_supported(log_n, plan)) continue;
+        const double cost = (double)plan.W * ((double)((u64)1 << log_n) * (c > 16 ? 1.04 : 1.0) + 4.5 * (double)(1u << (c - 1)));
+        if (!best || cost < best_cost) {
+            best = c;
+            best_cost = cost;
+        }
+    }
+    return best ? best : 4u;
 }
 
 // window width for precomputed tables: all windows share one bucket space, so wide windows are cheap --
-// minimise (additions) n * W(c) + (bucket reduction) alpha * 2^(c-1) over the widths the sort supports.  A bucket costs
-// about 4 additions' worth of time when the reduction kernels are busy (2^23 points and up) and up to 13 when they are
-// latency-bound (measured: 2^20 is fastest at 17 bits, 2^22 at 20, 2^23 and 2^24 at 22).
+// minimise (additions) n * W(c) + kBucketCost * 2^(c-1) over the widths the sort supports (2^20: 19 bits, 2^21 / 2^22: 20, 2^23 / 2^24: 22)
 unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 {
-    const double alpha = log_n >= 23 ? 4.0 : (log_n >= 22 ? 8.0 : 13.0);
     unsigned best = 0;
     double best_cost = 0;
-    for (unsigned c = 10; c <= 23; c++) {
+    for (unsigned c = 10; c <= 24; c++) {
         const panda::WindowPlan plan = panda::make_safe_window_plan(fr, c);
         if (plan.width[0] != c || !panda::msm_sort_tabled_supported(log_n, plan)) continue;
-        const double cost = (double)plan.W * (double)((u64)1 << log_n) + alpha * (double)(1u << (c - 1));
+        const double cost = (double)plan.W * (double)((u64)1 << log_n) + kBucketCost * (double)(1u << (c - 1));
         if (!best || cost < best_cost) {
             best = c;
             best_cost = cost;
@@ -242,7 +258,7 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 
 hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale, const panda::MsmPipeline *pipe)
 {
-    const panda::MsmTuning tuning{pick_window_bits(cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
+    const panda::MsmTuning tuning{pick_window_bits(panda::msm_scalar_field_of(curve), cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
                                   g_phase_timing.load(std::memory_order_relaxed)};
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
@@ -471,7 +487,7 @@ panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configur
 
 panda_error panda_msm_set_window_bits(unsigned window_bits)
 {
-    if (window_bits > 16) return panda_error_invalid_value;
+    if (window_bits > 20) return panda_error_invalid_value;
     g_window_override.store(window_bits, std::memory_order_relaxed);
     return panda_success;
 }

@@ -51,7 +51,9 @@ struct SortEvents {
     hipEvent_t digits_done, partition_done;
 };
 
-// Plain mode: W independent lists (one per window), entries index the caller's n bases.
+// Plain mode: W independent lists (one per window), entries index the caller's n bases.  Windows of up to 16 bits take a two-level
+// sort, wider ones (up to 2^19 buckets per window) the three levels of the tabled mode with one list per window.
+bool msm_sort_plain_supported(unsigned log_n, const WindowPlan &plan);
 size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
                           SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{});

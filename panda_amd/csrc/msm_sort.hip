@@ -474,6 +474,8 @@ struct TabledGeom {
     unsigned Q;          // H1 * H2 cells
     unsigned row_shift;  // final entries name row (k << row_shift) + row0 + i of the concatenated tables: log2 of the rows per table
     u32 row0;            // and the first row of the point range being sorted (both = log_n, 0 unless a call runs in point-range chunks)
+    unsigned per_window; // 0: one list, level 3 merges the W windows of a cell (tabled mode);  1: W lists, a level-3 cell is one window's
+                         // (plain mode with windows too wide for the two-level sort): cells are numbered window-major, entries name row0 + i
 };
 
 // one workgroup: seg_tile[0..S] = exclusive prefix of ceil(len_s / SORT_TILE)
@@ -665,15 +667,19 @@ __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsig
     len = so[h2 + 1] - so[h2];
 }
 
-// cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b
+// cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b.  per_window: cell q = k * Q + (h1 * H2 + h2)
+__device__ __forceinline__ unsigned cells_total(const TabledGeom &g) { return g.per_window ? g.W * g.Q : g.Q; }
+
 __global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g)
 {
     __shared__ u32 red[1024];
     const unsigned q = blockIdx.x * 1024 + threadIdx.x, t = threadIdx.x;
     u32 total = 0;
-    if (q < g.Q) {
-        const unsigned h1 = q / g.H2, h2 = q % g.H2;
-        for (unsigned k = 0; k < g.W; k++) {
+    if (q < cells_total(g)) {
+        const unsigned cell = g.per_window ? q % g.Q : q;
+        const unsigned h1 = cell / g.H2, h2 = cell % g.H2;
+        const unsigned k_begin = g.per_window ? q / g.Q : 0u, k_end = g.per_window ? k_begin + 1 : g.W;
+        for (unsigned k = k_begin; k < k_end; k++) {
             const u32 *so = sub_off + (u64)(k * g.H1 + h1) * (g.H2 + 1);
             total += so[h2 + 1] - so[h2];
         }
@@ -694,10 +700,11 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
     __shared__ u32 red[1024];
     __shared__ u32 sc[1024];
     const unsigned blk = blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
+    const unsigned Qt = cells_total(g);
     u32 v = 0;
     for (unsigned b = t; b < blk; b += 1024) v += blk_sum[b];
     red[t] = v;
-    const u32 mine = q < g.Q ? cell_cnt[q] : 0;
+    const u32 mine = q < Qt ? cell_cnt[q] : 0;
     sc[t] = mine;
     __syncthreads();
     for (unsigned s = 512; s > 0; s >>= 1) {
@@ -710,8 +717,8 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
         sc[t] += u;
         __syncthreads();
     }
-    if (q < g.Q) cell_off[q] = red[0] + sc[t] - mine;
-    if (q == g.Q - 1) cell_off[g.Q] = red[0] + sc[t];
+    if (q < Qt) cell_off[q] = red[0] + sc[t] - mine;
+    if (q == Qt - 1) cell_off[Qt] = red[0] + sc[t];
 }
 
 constexpr unsigned K3_THREADS = 1024;
@@ -726,14 +733,20 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     __shared__ u64 rbegin[64];
     __shared__ u32 rlen[64];
     __shared__ u32 vstart[65];
-    const unsigned q = blockIdx.x, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
+    // tabled mode: cell q of the one list, W runs to merge;  per-window mode: cell q of window k0's own list, one run
+    const unsigned k0 = g.per_window ? blockIdx.x / g.Q : 0u, q = g.per_window ? blockIdx.x % g.Q : blockIdx.x;
+    const unsigned nruns = g.per_window ? 1u : g.W;
     const unsigned h1 = q / g.H2, h2 = q % g.H2;
     const unsigned L = 1u << g.b3;
-    const u32 out_base = cell_off[q];
-    if (tid < g.W) {
+    // position of the cell's first entry within its list, and where the list starts in `sorted` / `off`
+    const u32 out_rel = cell_off[blockIdx.x] - (g.per_window ? cell_off[k0 * g.Q] : 0u);
+    u32 *sw = sorted + ((u64)k0 << g.log_n);
+    u32 *ow = off + (u64)k0 * (NB + 1);
+    if (tid < nruns) {
         u64 b;
         u32 len;
-        cell_run(b, len, tid, h1, h2, part_off, sub_off, g);
+        cell_run(b, len, k0 + tid, h1, h2, part_off, sub_off, g);
         rbegin[tid] = b;
         rlen[tid] = len;
     }
@@ -741,31 +754,34 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     __syncthreads();
     if (tid == 0) {
         u32 run = 0;
-        for (unsigned k = 0; k < g.W; k++) {
+        for (unsigned k = 0; k < nruns; k++) {
             vstart[k] = run;
             run += rlen[k];
         }
-        vstart[g.W] = run;
+        vstart[nruns] = run;
     }
     __syncthreads();
-    const u32 N = vstart[g.W]; // uniform over the block
+    const u32 N = vstart[nruns]; // uniform over the block
     const unsigned shift = g.log_n + 1;
     const u32 id_mask = (1u << g.log_n) - 1;
-    // virtual position in the concatenation of the W runs -> window
-    auto window_of = [&](u32 p) -> unsigned { // branch-free: the W - 1 broadcast reads pipeline
+    // virtual position in the concatenation of the runs -> run
+    auto window_of = [&](u32 p) -> unsigned { // branch-free: the broadcast reads pipeline
         unsigned k = 0;
-        for (unsigned j = 1; j < g.W; j++) k += p >= vstart[j] ? 1u : 0u;
+        for (unsigned j = 1; j < nruns; j++) k += p >= vstart[j] ? 1u : 0u;
         return k;
     };
-    // final word: row k*n + i of the tables, bit 31 = negate
-    auto final_word = [&](u32 v, unsigned k) -> u32 { return ((v & id_mask) + g.row0 + (k << g.row_shift)) | (((v >> g.log_n) & 1u) << 31); };
+    // final word: row k*n + i of the tables (tabled mode) or row i of the bases (per-window mode), bit 31 = negate
+    const unsigned table_shift = g.per_window ? 32u : g.row_shift;
+    auto final_word = [&](u32 v, unsigned k) -> u32 {
+        return ((v & id_mask) + g.row0 + (table_shift < 32 ? (k << table_shift) : 0u)) | (((v >> g.log_n) & 1u) << 31);
+    };
 
     if (N <= K3_CAP) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
         // (the cell's buckets are adjacent in the output)
         u32 word[K3_PER];
         unsigned char lo[K3_PER];
-        unsigned k = 0; // a thread's positions grow by K3_THREADS, about one run: the window only ever steps forward
+        unsigned k = 0; // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
             const u32 p = tid + j * K3_THREADS;
@@ -783,9 +799,9 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         if (tid < L) {
             const u32 start = cnt[tid] - mine; // local
             cur[tid] = start;
-            off[((u64)q << g.b3) + tid] = out_base + start;
+            ow[((u64)q << g.b3) + tid] = out_rel + start;
         }
-        if (q == g.Q - 1 && tid == 0) off[NB] = out_base + N;
+        if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel + N;
         __syncthreads();
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
@@ -793,7 +809,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
             if (p < N) outbuf[atomicAdd(&cur[lo[j]], 1u)] = word[j];
         }
         __syncthreads();
-        for (u32 p = tid; p < N; p += K3_THREADS) sorted[out_base + p] = outbuf[p];
+        for (u32 p = tid; p < N; p += K3_THREADS) sw[out_rel + p] = outbuf[p];
         return;
     }
 
@@ -811,16 +827,16 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         __syncthreads();
     }
     if (tid < L) {
-        u32 start = out_base + cnt[tid] - mine;
+        u32 start = out_rel + cnt[tid] - mine;
         cur[tid] = start;
-        off[((u64)q << g.b3) + tid] = start;
+        ow[((u64)q << g.b3) + tid] = start;
     }
-    if (q == g.Q - 1 && tid == 0) off[NB] = out_base + N;
+    if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel + N;
     __syncthreads();
     for (u32 p = tid; p < N; p += K3_THREADS) {
         const unsigned k = window_of(p);
         const u32 v = p2[rbegin[k] + (p - vstart[k])];
-        sorted[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
+        sw[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
     }
 }
 
@@ -837,16 +853,18 @@ SortGeom plain_geom(unsigned log_n, unsigned c)
     return g;
 }
 
-TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan)
+TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan, bool per_window = false)
 {
     TabledGeom g{};
     const unsigned B = plan.width[0] - 1;
     g.log_n = log_n;
     g.W = plan.W;
+    g.per_window = per_window ? 1u : 0u;
     g.b3 = std::min(std::min(7u, 31u - log_n), B);
-    // a level-3 cell (2^b3 buckets of all windows) should fit k3_merge's register-resident path: mean entries per cell
-    // = W n 2^b3 / 2^B, kept below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars)
-    while (g.b3 > 3 && (((u64)plan.W << log_n) >> (B - g.b3)) > (u64)K3_CAP * 4 / 5) g.b3--;
+    // a level-3 cell (2^b3 buckets of all windows, or of one) should fit k3_merge's register-resident path: mean entries per cell
+    // = W n 2^b3 / 2^B (n 2^b3 / 2^B per window), kept below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars)
+    const u64 per_bucket_bits = per_window ? ((u64)1 << log_n) : ((u64)plan.W << log_n);
+    while (g.b3 > 3 && (per_bucket_bits >> (B - g.b3)) > (u64)K3_CAP * 4 / 5) g.b3--;
     const unsigned rest = B - g.b3;
     g.b1 = (rest + 1) / 2;
     g.b2 = rest - g.b1;
@@ -940,8 +958,21 @@ static WindowPlan safe_plan(unsigned c)
 
 WindowPlan make_safe_window_plan(unsigned fr, unsigned c) { return fr == 0 ? safe_plan<Bn254Fr>(c) : (fr == 1 ? safe_plan<Bls377Fr>(c) : safe_plan<Bls381Fr>(c)); }
 
+static bool sort3_supported(unsigned log_n, const WindowPlan &plan, bool per_window);
+static size_t sort3_bytes(unsigned log_n, const WindowPlan &plan, bool per_window);
+static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev, SortResult *out,
+                        SortPlacement place, SampleCheck check, bool per_window);
+
+bool msm_sort_plain_supported(unsigned log_n, const WindowPlan &plan)
+{
+    const unsigned c = plan.width[0];
+    if (c <= 16) return c >= 2 && plain_geom(log_n, c).H <= MAX_PARTS;
+    return sort3_supported(log_n, plan, true);
+}
+
 size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
 {
+    if (plan.width[0] > 16) return sort3_bytes(log_n, plan, true);
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
     const SortGeom g = plain_geom(log_n, c);
@@ -952,9 +983,11 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan)
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
                           SortResult *out, SortPlacement place, SampleCheck check)
 {
+    // windows wider than 16 bits (u32 digit codes, 2^16 .. 2^19 buckets per window) take the three-level sort, a list per window
+    if (plan.width[0] > 16) return sort3(stream, arena, fr, scalars, log_n, plan, ev, out, place, check, true);
     const u64 n = (u64)1 << log_n;
     const unsigned W = plan.W, c = plan.width[0], NB = 1u << (c - 1);
-    if (c > 16 || c < 2) return hipErrorInvalidValue;
+    if (c < 2) return hipErrorInvalidValue;
     SortGeom geom = plain_geom(log_n, c);
     if (geom.H > MAX_PARTS) return hipErrorInvalidValue;
     if (place.row_shift) {
@@ -989,39 +1022,43 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
     return hipGetLastError();
 }
 
-bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan)
+static bool sort3_supported(unsigned log_n, const WindowPlan &plan, bool per_window)
 {
     const unsigned c = plan.width[0];
     if (plan.W > 32 || plan.W < 1 || c < 4 || c > 24 || log_n > 26 || log_n < 1) return false;
     unsigned wbits = 0;
     while ((1u << wbits) < plan.W) wbits++;
     if (log_n + wbits > 31) return false;
-    const TabledGeom g = tabled_geom(log_n, plan);
+    const TabledGeom g = tabled_geom(log_n, plan, per_window);
     return g.b1 <= 10 && g.b2 <= 8 && g.b3 <= 7 && g.S <= 16384 && g.b3 + 1 + log_n <= 32;
 }
 
-size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan)
+static size_t sort3_bytes(unsigned log_n, const WindowPlan &plan, bool per_window)
 {
     const u64 E = (u64)plan.W << log_n;
     const unsigned NB = 1u << (plan.width[0] - 1);
-    const TabledGeom g = tabled_geom(log_n, plan);
+    const TabledGeom g = tabled_geom(log_n, plan, per_window);
     const unsigned tiles1 = (unsigned)((((u64)1 << log_n) + SORT_TILE - 1) / SORT_TILE);
+    const size_t cells = (size_t)g.Q * (per_window ? g.W : 1u), lists = per_window ? g.W : 1u;
     return align256(E * 4 + 16) + 2 * align256((size_t)g.W * tiles1 * g.H1 * 4) + 2 * align256((size_t)g.W * (g.H1 + 1) * 4) + align256(E * 4 + 64) + align256(E + 16) +
            align256((size_t)(g.S + 1) * 4) + 2 * align256((size_t)g.max_tiles2 * g.H2 * 4) + align256((size_t)g.S * g.H2 * 4) +
-           align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((size_t)(g.Q + 1) * 4) + align256((size_t)(g.Q / 1024 + 1) * 4) +
-           align256((size_t)(NB + 1) * 4) + align256(E * 4) + 8192;
+           align256((size_t)g.S * (g.H2 + 1) * 4) + align256(E * 4) + 2 * align256((cells + 1) * 4) + align256((cells / 1024 + 1) * 4) +
+           align256(lists * (NB + 1) * 4) + align256(E * 4) + 8192;
 }
 
-hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out, SortPlacement place, SampleCheck check)
+// the three-level sort: tabled mode (one list over all windows) or per-window mode (W lists)
+static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev, SortResult *out,
+                        SortPlacement place, SampleCheck check, bool per_window)
 {
-    if (!msm_sort_tabled_supported(log_n, plan)) return hipErrorInvalidValue;
+    if (!sort3_supported(log_n, plan, per_window)) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
     const u64 E = (u64)plan.W << log_n;
     const unsigned W = plan.W, NB = 1u << (plan.width[0] - 1);
-    TabledGeom g = tabled_geom(log_n, plan);
-    if (place.row_shift) { // a point range [row0, row0 + n) of tables that hold 2^row_shift rows each
-        if (place.row_shift < log_n || place.row_shift > 26 || (((u64)(W - 1) << place.row_shift) + place.row0 + n) > ((u64)1 << 31)) return hipErrorInvalidValue;
+    TabledGeom g = tabled_geom(log_n, plan, per_window);
+    if (place.row_shift) { // a point range [row0, row0 + n) of tables that hold 2^row_shift rows each (per-window mode: of the base array)
+        if (place.row_shift < log_n || place.row_shift > 26) return hipErrorInvalidValue;
+        const u64 last_row = (per_window ? 0 : ((u64)(W - 1) << place.row_shift)) + place.row0 + n;
+        if (last_row > ((u64)1 << 31)) return hipErrorInvalidValue;
         g.row_shift = place.row_shift;
         g.row0 = place.row0;
     }
@@ -1031,7 +1068,8 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     g1.lo_bits = g.b2 + g.b3;
     g1.H = g.H1;
     g1.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
-    const unsigned qblocks = (g.Q + 1023) / 1024;
+    const unsigned cells = g.Q * (per_window ? W : 1u), lists = per_window ? W : 1u;
+    const unsigned qblocks = (cells + 1023) / 1024;
 
     u32 *d_dig = (u32 *)arena.take(E * 4 + 16);
     u32 *d_thist1 = (u32 *)arena.take((size_t)W * g1.tiles * g.H1 * 4);
@@ -1046,10 +1084,10 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     u32 *d_tot2 = (u32 *)arena.take((size_t)g.S * g.H2 * 4);
     u32 *d_suboff = (u32 *)arena.take((size_t)g.S * (g.H2 + 1) * 4);
     u32 *d_p2 = (u32 *)arena.take(E * 4);
-    u32 *d_cellcnt = (u32 *)arena.take((size_t)g.Q * 4);
+    u32 *d_cellcnt = (u32 *)arena.take((size_t)cells * 4);
     u32 *d_blksum = (u32 *)arena.take((size_t)qblocks * 4);
-    u32 *d_celloff = (u32 *)arena.take((size_t)(g.Q + 1) * 4);
-    u32 *d_off = (u32 *)arena.take((size_t)(NB + 1) * 4);
+    u32 *d_celloff = (u32 *)arena.take((size_t)(cells + 1) * 4);
+    u32 *d_off = (u32 *)arena.take((size_t)lists * (NB + 1) * 4);
     u32 *d_sorted = (u32 *)arena.take(E * 4);
     if (!d_dig || !d_thist1 || !d_tpref1 || !d_tpref2 || !d_poff || !d_ptot || !d_p1_lo || !d_p1_hi || !d_segtile || !d_thist2 || !d_tot2 || !d_suboff || !d_p2 || !d_cellcnt || !d_blksum || !d_celloff ||
         !d_off || !d_sorted)
@@ -1073,13 +1111,22 @@ hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const 
     // level 3, per cell
     hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_suboff, d_cellcnt, d_blksum, g);
     hipLaunchKernelGGL(k3_cell_offsets, dim3(qblocks), dim3(1024), 0, stream, d_cellcnt, d_blksum, d_celloff, g);
-    hipLaunchKernelGGL(k3_merge, dim3(g.Q), dim3(K3_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB);
+    hipLaunchKernelGGL(k3_merge, dim3(cells), dim3(K3_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB);
     out->off = d_off;
     out->sorted = d_sorted;
-    out->lists = 1;
+    out->lists = lists;
     out->NB = NB;
-    out->stride = E;
+    out->stride = per_window ? n : E;
     return hipGetLastError();
+}
+
+bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan) { return sort3_supported(log_n, plan, false); }
+size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan) { return sort3_bytes(log_n, plan, false); }
+
+hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
+                           SortResult *out, SortPlacement place, SampleCheck check)
+{
+    return sort3(stream, arena, fr, scalars, log_n, plan, ev, out, place, check, false);
 }
 
 } // namespace panda

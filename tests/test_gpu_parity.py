@@ -238,6 +238,48 @@ def test_msm_window_override(gm, wbits):
     assert (affine_of(0, out) == po.expected_from_linearity(0, 91, scalars)).all()
 
 
+@pytest.mark.parametrize("cid,k,wbits,kind", [(0, 14, 17, "uniform"), (0, 16, 19, "uniform"), (0, 15, 20, "small"), (0, 16, 20, "top_bit"), (0, 13, 18, "equal"),
+                                              (1, 14, 19, "uniform"), (2, 13, 20, "uniform")])
+def test_msm_plain_path_wide_windows(gm, cid, k, wbits, kind):
+    """The plain drop-in call (nothing registered) with windows wider than 16 bits: u32 digit codes and the three-level sort with a
+    bucket space per window (what the policy picks from 2^22 points on; forced here at sizes the suite affords).  Result checked by
+    MSM(s, m*G) = (sum s_i m_i)*G, scalar sets incl. the top-window carry and skew into a single bucket."""
+    lib = ffi.load()
+    n = 1 << k
+    db, ds, dr = DeviceBuffer(n * 2 * po.LC_Q[cid] * 4), DeviceBuffer(n * 32), DeviceBuffer(3 * po.LC_Q[cid] * 4)
+    ffi.check(lib.panda_gen_bases(cid, 7700 + k, 0, n, db.ptr, NULL_STREAM), "gen")
+    c = pyref.CURVES[cid]
+    rng = np.random.default_rng(k)
+    mont = lambda v: pyref.int_to_limbs(v * c.Rr % c.r, 8)
+    scalars = po.gen_scalars(po.FR_OF[cid], 7800 + k, n)
+    if kind == "small":
+        scalars = np.stack([mont(int(v)) for v in rng.integers(0, 1 << 16, n)])
+    elif kind == "top_bit":  # r - small: every window's digit carries into the next, the top window included
+        scalars = np.stack([mont(c.r - 1 - int(v)) for v in rng.integers(0, 1 << 20, n)])
+    elif kind == "equal":
+        scalars[:] = scalars[0]
+    scalars = np.ascontiguousarray(scalars)
+    ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(scalars.ctypes.data), n * 32), "memcpy")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[cid]
+    ffi.check(lib.panda_msm_set_window_bits(wbits), "cfg")
+    try:
+        ffi.check(fn(cfg), "msm")
+        assert (ds.to_host().reshape(n, 8) == scalars).all()  # scalars untouched
+        got = po.to_affine(cid, dr.to_host())
+        # and through registered (converted, untabled) bases + the in-call upload pipeline over point ranges
+        ffi.check(lib.panda_msm_register_bases(cid, db.ptr, k, gm.exec_stream.raw), "register")
+        ffi.check(fn(cfg), "msm")
+        got_reg = po.to_affine(cid, dr.to_host())
+        ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
+    finally:
+        lib.panda_msm_set_window_bits(0)
+    want = po.expected_from_linearity(cid, 7700 + k, scalars)
+    assert (got == want).all() and (got_reg == want).all()
+    for d in (db, ds, dr):
+        d.free()
+
+
 @pytest.mark.parametrize("k", [10, 13])
 def test_msm_bls12_377(gm, k):
     n = 1 << k

@@ -54,7 +54,10 @@ def main():
         ffi.check(lib.panda_gen_scalars(curve, 2, 0, n, ds.ptr, NULL_STREAM), "gen")
         cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, 0)
         ffi.check(lib.panda_msm_register_bases(curve, db.ptr, k, gm.exec_stream.raw), "register")
-        print(f"curve {curve} 2^{k} plain registered      : " + run(lib, cfg, reps, names, fn), flush=True)
+        for pc in [int(x) for x in os.environ.get("PANDA_PLAIN_C", "0").split(",")]:  # plain-path window widths to force (0 = policy)
+            lib.panda_msm_set_window_bits(pc)
+            print(f"curve {curve} 2^{k} plain registered c={pc:2d}: " + run(lib, cfg, reps, names, fn), flush=True)
+        lib.panda_msm_set_window_bits(0)
         ref = dr.to_host().tobytes()
         ffi.check(lib.panda_msm_unregister_bases(db.ptr), "unregister")
         for wb in wbs:
