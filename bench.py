@@ -230,6 +230,20 @@ class MsmProblem:
         self.ctx.lib.panda_msm_last_phase_ms(ph)
         return list(ph)
 
+    def all_phases(self, reps: int = 3):
+        """Per-phase device times from `reps` extra, untimed calls with every phase timer on (the timed steps record the
+        accumulate kernel and the call's total only: each further event costs a few microseconds of idle GPU)."""
+        lib = self.ctx.lib
+        lib.panda_msm_set_phase_timing(2)
+        try:
+            rows = []
+            for _ in range(reps):
+                self.execute()
+                rows.append(self.phases())
+        finally:
+            lib.panda_msm_set_phase_timing(1)
+        return [sum(r[i] for r in rows) / len(rows) for i in range(8)]
+
     def release(self):
         if self.registered:
             self.ctx.lib.panda_msm_unregister_bases(self.bases.data_ptr())
@@ -394,7 +408,10 @@ def main():
     if rank == 0:
         names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
         mean = [sum(r[i] for r in acc_ms) / len(acc_ms) for i in range(8)]
-        acc_kernel_ms = mean[3]
+        acc_kernel_ms = mean[3]  # HIP events around k_accumulate on its launch stream, inside the timed steps
+        device_ms = mean[7]
+        mean = prob.all_phases()  # every phase: separate untimed calls
+
         achieved = BYTES_PER_POINT[0] * n / (acc_kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -431,6 +448,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT[0] * n, "kernel_ms": acc_kernel_ms},
             "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
+            "device_ms_per_step": device_ms,
         }
         if world == 1:
             ref_ms = reference_model_ms(log_n)
@@ -449,7 +467,7 @@ def main():
                                      "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s (a sub-millisecond launch at the nominal "
                                                     "2.4 GHz; this kernel sustains ~2.0 GHz at ~1240 W, profiles/r02_accumulate_stalls.txt)"}
 
-    failed = []
+    failed, soft_failed = [], []
 
     def leg(name, fn, soft=False):
         """Secondary figures never take the contract line down with them: a failure is reported in place of the number, the
@@ -459,8 +477,7 @@ def main():
             res = fn()
         except Exception as e:  # noqa: BLE001
             res = {"error": repr(e)[:300]}
-            if not soft:
-                failed.append(name)
+            (soft_failed if soft else failed).append(name)
         if rank == 0 and res is not None:
             out[name] = res
 
@@ -468,6 +485,11 @@ def main():
         leg("pcie_inclusive", lambda: pcie_inclusive(ctx, prob))
         if prob.tables > 1:
             leg("without_tables", lambda: without_tables(ctx, prob, max(2, args.steps // 2)))
+            if rank == 0 and "ms_per_step" in out.get("without_tables", {}):
+                wt = out["without_tables"]
+                out["config"]["plain_call_without_tables"] = {"registered_ms_per_step": round(wt["ms_per_step"], 3),
+                                                              "unregistered_ms_per_step": round(wt.get("unregistered", {}).get("ms_per_step", 0.0), 3),
+                                                              "windows": wt.get("windows")}
     prob.release()
 
     if not args.no_config4 and world & (world - 1) == 0 and world <= 64:
@@ -500,6 +522,8 @@ def main():
     if rank == 0:
         if failed:
             out["failed_legs"] = failed
+        if soft_failed:  # legs the builder could not rehearse on real hardware (RCCL with more than one rank): reported, exit code kept
+            out["soft_failed_legs"] = soft_failed
         print(json.dumps(out), flush=True)
     if world > 1:
         ctx.dist.barrier()
@@ -544,7 +568,7 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
                       "roofline_frac_hbm": BYTES_PER_POINT[curve] * prob.n / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if curve in MADS_PER_ADDITION and ph[3] > 0:
             # the bound that binds: one mixed addition per sorted entry -- W n with tables, windows * n without
-            additions = (prob.tables if prob.tables > 1 else plain_windows(curve, log_n)) * prob.n
+            additions = (prob.tables if prob.tables > 1 else plain_windows(ctx.lib, curve, log_n)) * prob.n
             mads = additions * MADS_PER_ADDITION[curve] / (ph[3] * 1e-3)
             res[label]["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12, "unit": "T mad lane-ops/s",
                                             "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions, "mads_per_addition": MADS_PER_ADDITION[curve]}
@@ -555,11 +579,11 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
     return res
 
 
-def plain_windows(curve: int, log_n: int) -> int:
-    """windows of the plain (no tables) path: c = clamp(log_n - 4, 4, 16) bits (pick_window_bits, csrc/msm.hip) over the scalar field's bits"""
-    c = min(max(log_n - 4, 4), 16)
-    bits = {0: 254, 1: 253, 2: 255, 3: 254}[curve]
-    return -(-bits // c)
+def plain_windows(lib, curve: int, log_n: int) -> int:
+    """windows of the plain (no tables) path as the library's policy plans them (pick_window_bits, csrc/msm.hip)"""
+    bits, windows = C.c_uint(0), C.c_uint(0)
+    lib.panda_msm_plain_window_plan(curve, log_n, C.byref(bits), C.byref(windows))
+    return windows.value
 
 
 def without_tables(ctx: Ctx, prob: MsmProblem, steps: int) -> dict:
@@ -567,7 +591,10 @@ def without_tables(ctx: Ctx, prob: MsmProblem, steps: int) -> dict:
     panda_msm_execute_bn254 on resident pointers, which converts the bases' radix inside every call (run after the timed region)."""
     prob.register(False)
     dt = ctx.timed(lambda _t: prob.execute(), 1, steps) / steps
-    res = {"ms_per_step": dt * 1e3, "value": prob.n / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": prob.phases()[3]}
+    wb, wn = C.c_uint(0), C.c_uint(0)
+    ctx.lib.panda_msm_plain_window_plan(prob.curve, prob.log_n, C.byref(wb), C.byref(wn))
+    res = {"ms_per_step": dt * 1e3, "value": prob.n / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": prob.phases()[3],
+           "windows": f"{wn.value} windows of {wb.value} bits"}
     ctx.ffi.check(ctx.lib.panda_msm_unregister_bases(prob.bases.data_ptr()), "unregister_bases")
     prob.registered = False
     dt = ctx.timed(lambda _t: prob.execute(), 1, steps) / steps

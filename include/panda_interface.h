@@ -195,6 +195,8 @@ panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configur
 
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */
 panda_error panda_msm_set_window_bits(unsigned window_bits);
+/* what the plain path (no precomputed tables) would run a 2^log_n-point MSM of `curve` with: widest window and number of windows */
+panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned *window_bits, unsigned *windows);
 /* sorted entries per thread of the bucket-accumulation kernel, for experiments: 0 = built-in policy (rounded up to a multiple of 4) */
 panda_error panda_msm_set_chunk_entries(unsigned entries);
 /* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = the call's total only,

@@ -492,6 +492,16 @@ panda_error panda_msm_set_window_bits(unsigned window_bits)
     return panda_success;
 }
 
+panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned *window_bits, unsigned *windows)
+{
+    if (curve > 3 || log_n > 26) return panda_error_invalid_value;
+    const unsigned fr = panda::msm_scalar_field_of(curve);
+    const panda::WindowPlan plan = panda::make_safe_window_plan(fr, pick_window_bits(fr, log_n));
+    if (window_bits) *window_bits = plan.width[0];
+    if (windows) *windows = plan.W;
+    return panda_success;
+}
+
 panda_error panda_msm_set_chunk_entries(unsigned entries)
 {
     if (entries > 1024) return panda_error_invalid_value;

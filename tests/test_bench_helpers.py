@@ -26,10 +26,16 @@ def test_reference_model_counts():
 
 
 def test_plain_window_counts():
+    """the plain path's window plan comes from the library's own policy (a host-side function: no GPU needed)"""
+    sys.path.insert(0, ROOT)
+    from panda_amd import gpu_ffi as ffi
+
     b = _bench()
-    assert b.plain_windows(0, 24) == 16 and b.plain_windows(0, 20) == 16  # 254 bits in 16-bit windows
-    assert b.plain_windows(1, 24) == 16                                    # BLS12-377 Fr: 253 bits
-    assert b.plain_windows(0, 12) == -(-254 // 8)
+    lib = ffi.load()
+    assert b.plain_windows(lib, 0, 22) == 16  # 254 (+1) bits in 16-bit windows at 2^21 and 2^22 points
+    assert b.plain_windows(lib, 0, 24) == 13  # 20-bit windows from 2^24 points on (round 4)
+    assert b.plain_windows(lib, 1, 24) == 13  # BLS12-377 Fr: 253 bits
+    assert 16 <= b.plain_windows(lib, 0, 12) <= 40
     assert b.MADS_PER_ADDITION[0] == 8 * 162 + 2 * 126 - 81
     assert b.MADS_PER_ADDITION[1] == 8 * 2 * 14 * 14 + 2 * (14 * 15 // 2 + 14 * 14) - 14 * 14
 
