@@ -456,6 +456,7 @@ PandaGpuError PandaMultiGpuManager::msm_bn254_with_cached_bases(Bytes scalars, s
         }
     } staged;
     std::vector<panda_msm_configuration> cfgs(G);
+    std::vector<const void *> h_scalars(G);
     for (size_t d = 0; d < G; d++) {
         if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
         void *ds = nullptr, *dr = nullptr;
@@ -465,12 +466,14 @@ PandaGpuError PandaMultiGpuManager::msm_bn254_with_cached_bases(Bytes scalars, s
         if (panda_malloc(&dr, 3 * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
         staged.ptrs.push_back(dr);
         staged.dev.push_back(devices_[d]);
-        if (panda_memcpy(ds, scalars.data + d * per * FIELD_ELEMENT_LEN, per * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
         cfgs[d] = panda_msm_configuration{managers[d].get_mem_pool(), managers[d].get_exec_stream(), d_bases_[d], ds, dr, bases_log_per_,
                                           managers[0].get_msm_result_coordinate_type()};
+        h_scalars[d] = scalars.data + d * per * FIELD_ELEMENT_LEN;
     }
     result->assign(3 * FIELD_ELEMENT_LEN, 0);
-    const bool ok = panda_msm_execute_bn254_multi(handle, cfgs.data(), result->data()) == 0;
+    // every device uploads its own shard inside the call, in point ranges beside its kernels (round 3 copied the G shards one after the
+    // other from this thread before anything ran: unit.rs:103-188 stages the same way)
+    const bool ok = panda_msm_execute_bn254_from_host_multi(handle, cfgs.data(), h_scalars.data(), 4, result->data()) == 0;
     (void)set_device((size_t)devices_[0]);
     return ok ? PandaGpuError::Ok : PandaGpuError::SchedulingErr;
 }

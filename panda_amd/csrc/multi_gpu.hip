@@ -86,6 +86,7 @@ struct MultiGpu {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;                 // used when a configuration carries no stream of its own
+    std::vector<hipStream_t> copy_streams;            // per device: the upload stream of the *_from_host_multi calls
     std::vector<void *> d_gather;                     // per device: n x MAX_RESULT_BYTES, partials of every rank
     std::vector<std::unique_ptr<Worker>> workers;
     std::vector<float> phase_ms;                      // n x PANDA_MSM_PHASES, from the workers' last MSM
@@ -118,6 +119,7 @@ struct MultiGpu {
         for (unsigned d = 0; d < n && d < devices.size(); d++) {
             (void)hipSetDevice(devices[d]);
             if (d < streams.size() && streams[d]) (void)hipStreamDestroy(streams[d]);
+            if (d < copy_streams.size() && copy_streams[d]) (void)hipStreamDestroy(copy_streams[d]);
             if (d < d_gather.size() && d_gather[d]) (void)hipFree(d_gather[d]);
         }
     }
@@ -126,7 +128,7 @@ struct MultiGpu {
 hipError_t from_nccl(ncclResult_t r, const char *what)
 {
     if (r == ncclSuccess) return hipSuccess;
-    printf("[panda-hip] RCCL error in %s: %s\n", what, ncclGetErrorString(r));
+    fprintf(stderr, "[panda-hip] RCCL error in %s: %s\n", what, ncclGetErrorString(r));
     return hipErrorUnknown;
 }
 #define PANDA_TRY_NCCL(expr) PANDA_TRY(from_nccl((expr), #expr))
@@ -142,10 +144,23 @@ hipError_t sync_all(MultiGpu &mg, const std::vector<hipStream_t> &streams)
     return hipSuccess;
 }
 
-typedef panda_error (*msm_fn)(const panda_msm_configuration);
 typedef panda_error (*combine_fn)(const void *, unsigned, panda_msm_result_coordinate_type, void *);
 
-hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *result, size_t rb, msm_fn execute, combine_fn combine)
+// an RCCL group that is closed on every path: a failing call between ncclGroupStart and ncclGroupEnd must not leave the thread's group
+// open (the next collective of this host thread would be queued into the stale group and could hang)
+template <class Body>
+hipError_t nccl_group(Body body)
+{
+    PANDA_TRY_NCCL(ncclGroupStart());
+    const hipError_t e = body();
+    const ncclResult_t end = ncclGroupEnd();
+    if (e != hipSuccess) return e;
+    return from_nccl(end, "ncclGroupEnd");
+}
+
+// `execute(d, cfg)`: the single-GPU call of rank d (synchronous), run on worker d with its device current
+hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *result, size_t rb, const std::function<panda_error(unsigned, const panda_msm_configuration &)> &execute,
+                     combine_fn combine)
 {
     if (!cfgs || !result) return hipErrorInvalidValue;
     std::lock_guard<std::mutex> call(mg.call_mutex);
@@ -158,7 +173,7 @@ hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *re
         panda_msm_configuration c = cfgs[d];
         c.msm_result_coordinate_type = JACOBIAN; // partials are added as Jacobian points; the requested form is produced by the combine
         c.stream.handle = streams[d];
-        const panda_error pe = execute(c);
+        const panda_error pe = execute(d, c);
         if (pe != panda_success) return static_cast<hipError_t>(pe);
         (void)panda_msm_last_phase_ms(&mg.phase_ms[d * PANDA_MSM_PHASES]);
         return hipMemcpyAsync((char *)mg.d_gather[d] + d * rb, c.results, rb, hipMemcpyDefault, streams[d]);
@@ -166,13 +181,11 @@ hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *re
     if (e == hipSuccess) {
         if (mg.transport == PANDA_MULTI_RCCL) {
             // one collective: every device ends with all partials (in place: the send buffer is the rank's own slot)
-            e = [&]() -> hipError_t {
-                PANDA_TRY_NCCL(ncclGroupStart());
+            e = nccl_group([&]() -> hipError_t {
                 for (unsigned d = 0; d < mg.n; d++)
                     PANDA_TRY_NCCL(ncclAllGather((char *)mg.d_gather[d] + d * rb, mg.d_gather[d], rb, ncclChar, mg.comms[d], streams[d]));
-                PANDA_TRY_NCCL(ncclGroupEnd());
                 return hipSuccess;
-            }();
+            });
         } else {
             e = sync_all(mg, streams);
             for (unsigned d = 0; e == hipSuccess && d < mg.n; d++) {
@@ -182,7 +195,9 @@ hipError_t msm_multi(MultiGpu &mg, const panda_msm_configuration *cfgs, void *re
             }
         }
     }
-    if (e == hipSuccess) e = sync_all(mg, streams);
+    // on every path, errors included: nothing of this call is in flight on the callers' streams when it returns
+    const hipError_t drained = sync_all(mg, streams);
+    if (e == hipSuccess) e = drained;
     if (e == hipSuccess) {
         std::vector<unsigned char> partials(mg.n * rb);
         e = hipSetDevice(mg.devices[0]);
@@ -227,16 +242,14 @@ hipError_t ntt_multi(MultiGpu &mg, const panda_ntt_slab_configuration *cfgs, sla
         }
         if (mg.transport == PANDA_MULTI_RCCL) {
             // the single exchange: chunk q of rank d -> chunk d of rank q, all pairs in one group (full mesh, one xGMI link per pair)
-            e = [&]() -> hipError_t {
-                PANDA_TRY_NCCL(ncclGroupStart());
+            e = nccl_group([&]() -> hipError_t {
                 for (unsigned d = 0; d < mg.n; d++)
                     for (unsigned q = 0; q < mg.n; q++) {
                         PANDA_TRY_NCCL(ncclSend(src[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], streams[d]));
                         PANDA_TRY_NCCL(ncclRecv(dst[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], streams[d]));
                     }
-                PANDA_TRY_NCCL(ncclGroupEnd());
                 return hipSuccess;
-            }();
+            });
         } else {
             e = sync_all(mg, streams); // every rank's step 1 is complete before anybody copies out of it
             for (unsigned d = 0; e == hipSuccess && d < mg.n; d++) {
@@ -257,6 +270,7 @@ hipError_t ntt_multi(MultiGpu &mg, const panda_ntt_slab_configuration *cfgs, sla
             if (pe != panda_success) return static_cast<hipError_t>(pe);
             return hipStreamSynchronize(streams[d]);
         });
+    if (e != hipSuccess) (void)sync_all(mg, streams); // nothing of a failed call stays in flight on the callers' streams
     if (e == hipSuccess)
         for (unsigned d = 0; d < mg.n; d++) {
             const char *out = flag[d] ? src[d] : dst[d];
@@ -288,12 +302,14 @@ panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, uns
     mg->transport = transport;
     mg->devices.assign(devices, devices + n_dev);
     mg->streams.assign(n_dev, nullptr);
+    mg->copy_streams.assign(n_dev, nullptr);
     mg->d_gather.assign(n_dev, nullptr);
     mg->phase_ms.assign((size_t)n_dev * PANDA_MSM_PHASES, 0.f);
     hipError_t e = hipSuccess;
     for (unsigned d = 0; e == hipSuccess && d < n_dev; d++) {
         e = hipSetDevice(devices[d]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->streams[d], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->copy_streams[d], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(&mg->d_gather[d], (size_t)n_dev * MAX_RESULT_BYTES);
     }
     if (e == hipSuccess && transport == PANDA_MULTI_RCCL) {
@@ -332,13 +348,46 @@ panda_error panda_multi_gpu_device_count(panda_multi_gpu mg, unsigned *n_dev)
 panda_error panda_msm_execute_bn254_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
 {
     if (!mg.handle) return panda_error_invalid_value;
-    return static_cast<panda_error>(msm_multi(*handle_of(mg), cfgs, result, 96, panda_msm_execute_bn254, panda_msm_combine_bn254));
+    return static_cast<panda_error>(
+        msm_multi(*handle_of(mg), cfgs, result, 96, [](unsigned, const panda_msm_configuration &c) { return panda_msm_execute_bn254(c); }, panda_msm_combine_bn254));
 }
 
 panda_error panda_msm_execute_bls12_377_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
 {
     if (!mg.handle) return panda_error_invalid_value;
-    return static_cast<panda_error>(msm_multi(*handle_of(mg), cfgs, result, 144, panda_msm_execute_bls12_377, panda_msm_combine_bls12_377));
+    return static_cast<panda_error>(
+        msm_multi(*handle_of(mg), cfgs, result, 144, [](unsigned, const panda_msm_configuration &c) { return panda_msm_execute_bls12_377(c); }, panda_msm_combine_bls12_377));
+}
+
+// Scalars that start on the HOST (north_star / SURVEY 8e: "scalars H2D'd per shard"; unit.rs:103-188 stages them before it executes):
+// every worker runs the in-call upload pipeline of panda_msm_execute_from_host on its own shard -- its own arena, helper stream, copy
+// stream and PCIe link -- so the G uploads run side by side and each hides behind its shard's kernels.
+static panda_error msm_from_host_multi(panda_multi_gpu mg, unsigned curve, size_t rb, combine_fn combine, const panda_msm_configuration *cfgs, const void *const *h_scalars,
+                                       unsigned ranges, void *result)
+{
+    if (!mg.handle || !h_scalars) return panda_error_invalid_value;
+    MultiGpu &m = *handle_of(mg);
+    for (unsigned d = 0; d < m.n; d++)
+        if (!h_scalars[d]) return panda_error_invalid_value;
+    return static_cast<panda_error>(msm_multi(
+        m, cfgs, result, rb,
+        [&m, curve, h_scalars, ranges](unsigned d, const panda_msm_configuration &c) {
+            panda_stream h2d;
+            h2d.handle = m.copy_streams[d];
+            return panda_msm_execute_from_host(curve, c, h_scalars[d], ranges, h2d);
+        },
+        combine));
+}
+
+panda_error panda_msm_execute_bn254_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges, void *result)
+{
+    return msm_from_host_multi(mg, 0, 96, panda_msm_combine_bn254, cfgs, h_scalars, ranges, result);
+}
+
+panda_error panda_msm_execute_bls12_377_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges,
+                                                        void *result)
+{
+    return msm_from_host_multi(mg, 1, 144, panda_msm_combine_bls12_377, cfgs, h_scalars, ranges, result);
 }
 
 panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)

@@ -83,6 +83,7 @@ ADDITIVE_SYMBOLS = [
     "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_ntt_slab_inverse_step1_bn254_enqueue", "panda_ntt_slab_inverse_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
     "panda_debug_field_op", "panda_debug_curve_op", "panda_version",
     "panda_multi_gpu_create", "panda_multi_gpu_destroy", "panda_multi_gpu_device_count", "panda_msm_execute_bn254_multi", "panda_msm_execute_bls12_377_multi",
+    "panda_msm_execute_bn254_from_host_multi", "panda_msm_execute_bls12_377_from_host_multi",
     "panda_ntt_execute_bn254_multi", "panda_ntt_execute_bn254_inverse_multi", "panda_multi_gpu_last_phase_ms",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
@@ -141,6 +142,8 @@ def load() -> C.CDLL:
         "panda_multi_gpu_create": [C.POINTER(PandaMultiGpu), C.POINTER(C.c_int), u, u], "panda_multi_gpu_destroy": [PandaMultiGpu],
         "panda_multi_gpu_device_count": [PandaMultiGpu, C.POINTER(u)],
         "panda_msm_execute_bn254_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp], "panda_msm_execute_bls12_377_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp],
+        "panda_msm_execute_bn254_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
+        "panda_msm_execute_bls12_377_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
         "panda_ntt_execute_bn254_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)], "panda_ntt_execute_bn254_inverse_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)],
         "panda_multi_gpu_last_phase_ms": [PandaMultiGpu, u, C.POINTER(C.c_float)],
     }

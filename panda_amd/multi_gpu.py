@@ -274,6 +274,17 @@ class MultiGpu:
         ffi.check(fn(self.handle, arr, C.c_void_p(out.ctypes.data)), "SchedulingErr")
         return out
 
+    def msm_from_host(self, cfgs, host_ptrs, ranges: int = 4, curve: int = 0) -> np.ndarray:
+        """panda_msm_execute_*_from_host_multi: as msm(), with rank d's scalars starting at host address host_ptrs[d] (pinned or
+        pageable) and crossing PCIe inside the call -- every device uploads its own shard, in `ranges` point ranges, beside its kernels."""
+        assert len(cfgs) == len(host_ptrs) == self.n and curve in (0, 1)
+        arr = (ffi.MSMConfiguration * self.n)(*cfgs)
+        hp = (C.c_void_p * self.n)(*[C.c_void_p(int(p)) for p in host_ptrs])
+        out = np.zeros(96 if curve == 0 else 144, dtype=np.uint8)
+        fn = self.lib.panda_msm_execute_bn254_from_host_multi if curve == 0 else self.lib.panda_msm_execute_bls12_377_from_host_multi
+        ffi.check(fn(self.handle, arr, hp, ranges, C.c_void_p(out.ctypes.data)), "SchedulingErr")
+        return out
+
     def ntt(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None):
         """panda_ntt_execute_bn254[_inverse]_multi on device pointers slabs[d] / scratches[d]; returns the flags (1: rank d's output is in
         scratches[d])."""

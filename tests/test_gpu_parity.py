@@ -555,6 +555,56 @@ def test_c_abi_multi_gpu_msm(gm, ranks, transport):
             d.free()
 
 
+@pytest.mark.parametrize("ranks,transport,pinned,tabled", [(1, ffi.MULTI_RCCL, True, True), (2, ffi.MULTI_LOOPBACK, True, True), (4, ffi.MULTI_LOOPBACK, False, True),
+                                                          (8, ffi.MULTI_LOOPBACK, True, False), (8, ffi.MULTI_LOOPBACK, False, True)])
+def test_c_abi_multi_gpu_msm_from_host(gm, ranks, transport, pinned, tabled):
+    """panda_msm_execute_bn254_from_host_multi: the scalars start on the HOST (pinned, or pageable) and every rank's worker uploads its
+    own shard inside the call, in point ranges beside its kernels (registered bases: with tables and without; 2^17 points per rank so
+    that the ranges are real).  Total by linearity over all scalars; the device staging buffers end up holding the scalars."""
+    k_per = 17
+    per, n = 1 << k_per, ranks << k_per
+    lib = ffi.load()
+    seed_b, seed_s = 0xBA5E + ranks, 0x5CA1 + ranks
+    db = DeviceBuffer(n * 64)
+    ffi.check(lib.panda_gen_bases(0, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    scalars = po.gen_scalars(po.F_BN254_FR, seed_s, n)
+    want = po.expected_from_linearity(0, seed_b, scalars)
+    host_ptr = C.c_void_p()
+    if pinned:
+        ffi.check(lib.panda_malloc_host(C.byref(host_ptr), n * 32), "malloc_host")
+        C.memmove(host_ptr, scalars.ctypes.data, n * 32)
+        host0 = host_ptr.value
+    else:
+        host0 = scalars.ctypes.data
+    staging = [DeviceBuffer(per * 32) for _ in range(ranks)]
+    results = [DeviceBuffer(96) for _ in range(ranks)]
+    base_ptrs = [C.c_void_p(db.ptr.value + r * per * 64) for r in range(ranks)]
+    for bp in base_ptrs:
+        if tabled:
+            ffi.check(lib.panda_msm_precompute_bases(0, bp, k_per, 0, NULL_STREAM), "precompute")
+        else:
+            ffi.check(lib.panda_msm_register_bases(0, bp, k_per, NULL_STREAM), "register")
+    mg = multi_gpu.MultiGpu([0] * ranks, transport)
+    try:
+        for coord, ranges in ((pgm.JACOBIAN, 2), (pgm.PROJECTIVE, 1), (pgm.JACOBIAN, 4)):
+            cfgs = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), base_ptrs[r], staging[r].ptr, results[r].ptr, k_per, coord) for r in range(ranks)]
+            total = mg.msm_from_host(cfgs, [host0 + r * per * 32 for r in range(ranks)], ranges)
+            assert (affine_of(0, total, coord) == want).all()
+        r = ranks - 1
+        assert (staging[r].to_host().reshape(per, 8) == scalars[r * per:(r + 1) * per]).all()
+        with pytest.raises(ffi.PandaGpuError):
+            mg.msm_from_host(cfgs, [host0] * (ranks - 1) + [0], 2)  # a missing host source is refused before anything is enqueued
+        assert (affine_of(0, mg.msm(cfgs), pgm.JACOBIAN) == want).all()  # the resident-scalars call on what the upload left behind
+    finally:
+        mg.close()
+        for bp in base_ptrs:
+            lib.panda_msm_unregister_bases(bp)
+        if pinned:
+            lib.panda_free_host(host_ptr)
+        for d in [db] + staging + results:
+            d.free()
+
+
 @pytest.mark.parametrize("ranks,transport,log_n", [(1, ffi.MULTI_RCCL, 12), (2, ffi.MULTI_LOOPBACK, 9), (4, ffi.MULTI_LOOPBACK, 14), (8, ffi.MULTI_LOOPBACK, 21)])
 def test_c_abi_multi_gpu_ntt(gm, ranks, transport, log_n):
     """panda_ntt_execute_bn254_multi / _inverse_multi: step 1 -> all-to-all -> step 2 behind one C call (grouped ncclSend / ncclRecv on
