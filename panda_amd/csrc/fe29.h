@@ -647,7 +647,13 @@ PANDA_HD void fe_reduce_small(Fe<F> &a)
 //
 //   fe_mul_shoup   needs  limb(x) < 3 * 2^30 + 64 (tight, loose, or the output of fe_sub_raw / fe_sub_raw_bias: nine such limbs times a
 //                         29-bit limb of the constant, plus the nine q * (R - p) terms of the low half, stay below 2^64), value(x) < R for the bound given
-//                  gives  tight, value < 3p  (exactly: < (x / R + 2) p)
+//                  gives  tight, value < 3p  (from the estimate above: < (x / R + 2) p)
+// The bound that callers which PACK the result into 32 L bits rely on is tighter.  The truncated quotient product differs from
+// Q = floor(x wq / R) only by a borrow out of the dropped columns, which are worth less than N 2^-29 < 2^-23 of a unit of q: the computed
+// q is Q - 1 only when frac(x wq / R) < 2^-23, and Q otherwise.  Either way q > x wq / R - 1 - 2^-23 >= x w / p - x / R - 1 - 2^-23, so
+//                         value < (1 + x / R + 2^-23) p
+// -- below 2^(32 L) for every field here as long as x / R stays below about one (BLS12-381 Fr, p = 0.453 2^256, is the tightest:
+// k_ntt_pass8 asserts it for the bound its plan gives the operand).
 template <class F>
 struct FeTw {
     u32 w[F::N];  // the constant, canonical

@@ -262,7 +262,6 @@ struct PassArgs {
     unsigned canonical;   // reduce the outputs to [0, p): the last pass of a transform; earlier passes stop at [0, 2p)
     unsigned br_in;       // first pass only: the caller's input is in bit-reversed order (element j sits at bitrev(j))
     unsigned br_out;      // last pass only: leave the output in bit-reversed order (y[k] goes to bitrev(k))
-    unsigned tw_done;     // the previous pass (k_ntt_pass8) multiplied the inter-pass twiddle onto its outputs: none here
 };
 
 template <class Fr, int DEG>
@@ -303,7 +302,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
         const unsigned blk = blk0 + b;
         Fe<Fr> v;
         load_elem(v, A.x + src_index * 8);
-        if ((A.lgp != 0 && !A.tw_done) || A.force_tw) {
+        if (A.lgp != 0 || A.force_tw) {
             const unsigned k = blk & (p - 1);
             if (k * i != 0 || A.force_tw) {
                 Fe<Fr> tw;
@@ -335,11 +334,11 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs A)
     const bool active = tid < (TE >> 1);
     // every thread passes the DEG barriers of the rounds; threads beyond a short tile only wait
     if (active)
-        Rounds<Fr, DEG, 0, 3>::run(u, pq, sub * R, t, tid, TE == TILE); // inputs below 3p: what k_ntt_pass8's twiddle product leaves
+        Rounds<Fr, DEG, 0, 2>::run(u, pq, sub * R, t, tid, TE == TILE); // inputs below 2p: the caller's canonical elements, this kernel's own inter-pass outputs, or a fe_mul result
     else
         for (int r = 0; r < DEG; r++) __syncthreads();
 
-    constexpr int FB = Rounds<Fr, DEG, 0, 3>::FINAL;
+    constexpr int FB = Rounds<Fr, DEG, 0, 2>::FINAL;
     static_assert(FB < 512, "final bound must fit fe_reduce_small (values below 2^9 p)");
     for (unsigned e = tid; e < TE; e += 512) {
         unsigned b, i, lds_i;
@@ -733,9 +732,9 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             a.lgp = log_p;
             a.tile_elems = (unsigned)std::min<u64>(TILE, n);
             const unsigned mbits = log_p + deg; // bits of the twiddle exponent k * i
-            a.tw_done = (regs8 && log_p != 0) ? 1 : 0;
-            a.split = (log_p != 0 && mbits > 16 && !a.tw_done) ? 16 - deg : 0;
-            a.force_tw = (scale && last && !regs8) ? 1 : 0; // with k_ntt_pass8 in front the scale sits in the first pass's output twiddles
+            // (this kernel only runs transforms below 2^11 points: from there on every pass is k_ntt_pass8 / k_ntt_small, see above)
+            a.split = (log_p != 0 && mbits > 16) ? 16 - deg : 0;
+            a.force_tw = (scale && last) ? 1 : 0;
             a.strided_out = 0;
             a.canonical = last ? 1 : 0;
             a.br_in = (br_in && passes == 0) ? 1 : 0;
@@ -743,7 +742,7 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             if (build) {
                 fe_pow_u64(base, omega, n >> deg); // butterfly twiddles (w^(n >> deg))^t
                 build_table<Fr>(stream, base, nullptr, std::max(1u, (1u << deg) >> 1), d_pq);
-                if (log_p != 0 && !a.tw_done) {
+                if (log_p != 0) {
                     fe_pow_u64(base, omega, n >> log_p >> deg);
                     if (a.split == 0)
                         build_table<Fr>(stream, base, a.force_tw ? scale : nullptr, 1u << mbits, d_ta);

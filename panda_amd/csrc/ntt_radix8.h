@@ -370,6 +370,10 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     }
     constexpr int FB = PL.b[8];
     static_assert(FB < (int)Fr::HEADROOM && FB < 512, "final bound");
+    // the output product of a pass that is not the last is stored as a 32-byte element: its value, below (1 + x / R + 2^-23) p with
+    // x < FB p (fe29.h, fe_mul_shoup), must stay below 2^(32 L).  p < (PW[L-1] + 1) 2^(32 (L-1)) and x / R < FB / HEADROOM:
+    static_assert(LAST || ((unsigned long long)(Fr::HEADROOM + FB + 1) * ((unsigned long long)Fr::PW[Fr::L - 1] + 1) < (unsigned long long)Fr::HEADROOM << 32),
+                  "an inter-pass output product would not fit the 32-byte element");
 
     // ---- output: register m holds output i_out = 32 bitrev3(m) + bitrev5(q) of sub-transform blk = blk0 + s
     const unsigned blk = blk0 + s;

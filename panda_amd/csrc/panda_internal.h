@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/panda_interface.h"
 
@@ -66,22 +67,15 @@ void registry_forget_allocation(const void *ptr);
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Boundary check for caller buffers: true when `ptr` lies in an allocation the runtime can describe and that allocation ends
-// before ptr + bytes.  A caller that passes a buffer shorter than log_n implies (round 2: a 4 KB buffer with log_n = 10 on a
-// 128-byte-per-point curve) would otherwise make a kernel read past it and take the process down; with this the entry point
-// answers panda_error_invalid_value.  Pointers the runtime does not know (host memory, other allocators' sub-ranges it cannot
-// resolve) pass: the check can only ever refuse what is provably too short.
-static inline bool extent_too_short(const void *ptr, size_t bytes)
-{
-    if (!ptr || !bytes) return false;
-    hipDeviceptr_t base = nullptr;
-    size_t size = 0;
-    if (hipMemGetAddressRange(&base, &size, const_cast<void *>(ptr)) != hipSuccess || !base || !size) {
-        (void)hipGetLastError();
-        return false;
-    }
-    const size_t off = (size_t)((const char *)ptr - (const char *)base);
-    return off > size || size - off < bytes;
-}
+// Boundary check for caller buffers: true when `ptr` lies in an allocation made through this library (panda_malloc,
+// panda_malloc_from_pool_async: shim.hip keeps their extents) and that allocation ends before ptr + bytes.  A caller that passes a
+// buffer shorter than log_n implies (round 2: a 4 KB buffer with log_n = 10 on a 128-byte-per-point curve) would otherwise make a
+// kernel read past it and take the process down; with this the entry point answers panda_error_invalid_value.  Pointers from other
+// allocators pass unchecked: the runtime's own description of them (hipMemGetAddressRange, which round 3 used) is one mapped CHUNK for
+// virtual-memory mappings such as torch's expandable segments, so a valid buffer spanning several chunks would be refused -- the check
+// only ever refuses what is provably too short.  No runtime call: a lookup in a small ordered map.
+bool extent_too_short(const void *ptr, size_t bytes);
+void track_allocation(const void *ptr, size_t bytes);
+void untrack_allocation(const void *ptr);
 
 } // namespace panda

@@ -4,7 +4,48 @@
 // reference's 28 thin wrappers (src/cuda/core/panda_interface.cu:11-154) and of the two helpers in
 // src/cuda/core/common/common.cu:11-29 (blocking-sync stream, device memory pool with an unlimited
 // release threshold).  Written against the HIP runtime directly; there is no CUDA path.
+#include <map>
+#include <mutex>
+
 #include "panda_internal.h"
+
+namespace panda {
+
+namespace {
+std::mutex g_alloc_mutex;
+// deliberately never destroyed (allocations may be freed from static destructors of the host program)
+std::map<uintptr_t, size_t> &g_allocs = *new std::map<uintptr_t, size_t>();
+} // namespace
+
+void track_allocation(const void *ptr, size_t bytes)
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    g_allocs[(uintptr_t)ptr] = bytes;
+}
+
+void untrack_allocation(const void *ptr)
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    g_allocs.erase((uintptr_t)ptr);
+}
+
+bool extent_too_short(const void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return false;
+    const uintptr_t p = (uintptr_t)ptr;
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    auto it = g_allocs.upper_bound(p); // first allocation that starts behind p
+    if (it == g_allocs.begin()) return false;
+    --it;
+    const uintptr_t base = it->first;
+    const size_t size = it->second;
+    if (p - base >= size) return false; // not inside an allocation of ours
+    return size - (p - base) < bytes;
+}
+
+} // namespace panda
 
 extern "C" {
 
@@ -70,13 +111,19 @@ panda_error panda_event_destroy(panda_event event) { return static_cast<panda_er
 
 panda_error panda_mem_get_info(size_t *free, size_t *total) { return static_cast<panda_error>(hipMemGetInfo(free, total)); }
 
-panda_error panda_malloc(void **ptr, size_t size) { return static_cast<panda_error>(hipMalloc(ptr, size)); }
+panda_error panda_malloc(void **ptr, size_t size)
+{
+    const hipError_t e = hipMalloc(ptr, size);
+    if (e == hipSuccess && ptr) panda::track_allocation(*ptr, size);
+    return static_cast<panda_error>(e);
+}
 
 panda_error panda_malloc_host(void **ptr, size_t size) { return static_cast<panda_error>(hipHostMalloc(ptr, size, hipHostMallocDefault)); }
 
 panda_error panda_free(void *ptr)
 {
     panda::registry_forget_allocation(ptr); // a cached-bases registration must not survive its buffer (msm.hip)
+    panda::untrack_allocation(ptr);
     return static_cast<panda_error>(hipFree(ptr));
 }
 
@@ -123,12 +170,15 @@ panda_error panda_mem_pool_destroy(panda_mem_pool pool) { return static_cast<pan
 
 panda_error panda_malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool pool, panda_stream stream)
 {
-    return static_cast<panda_error>(hipMallocFromPoolAsync(ptr, size, static_cast<hipMemPool_t>(pool.handle), static_cast<hipStream_t>(stream.handle)));
+    const hipError_t e = hipMallocFromPoolAsync(ptr, size, static_cast<hipMemPool_t>(pool.handle), static_cast<hipStream_t>(stream.handle));
+    if (e == hipSuccess && ptr) panda::track_allocation(*ptr, size);
+    return static_cast<panda_error>(e);
 }
 
 panda_error panda_free_async(void *ptr, panda_stream stream)
 {
     panda::registry_forget_allocation(ptr);
+    panda::untrack_allocation(ptr);
     return static_cast<panda_error>(hipFreeAsync(ptr, static_cast<hipStream_t>(stream.handle)));
 }
 

@@ -327,6 +327,62 @@ def test_msm_bls12_377_2_16_linearity(gm):
     assert (po.to_affine(1, out) == po.expected_from_linearity(1, 0x70616E6461 ^ 5, scalars)).all()
 
 
+def test_msm_bases_in_a_virtual_memory_mapping(gm):
+    """Caller buffers are checked against log_n at the boundary, but only against allocations made through the library itself: for memory
+    mapped with hipMemAddressReserve / hipMemMap (torch's expandable segments) the runtime's own description of a pointer may be a single
+    mapped chunk, and a base buffer that legitimately spans two chunks must not be refused (panda_internal.h)."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+    except OSError:
+        pytest.skip("no HIP runtime library to map memory with")
+
+    class Loc(C.Structure):
+        _fields_ = [("type", C.c_int), ("id", C.c_int)]
+
+    class Prop(C.Structure):
+        _fields_ = [("type", C.c_int), ("requestedHandleType", C.c_int), ("location", Loc), ("win32HandleMetaData", C.c_void_p),
+                    ("compressionType", C.c_ubyte), ("gpuDirectRDMACapable", C.c_ubyte), ("usage", C.c_ushort)]
+
+    class Access(C.Structure):
+        _fields_ = [("location", Loc), ("flags", C.c_int)]
+
+    prop = Prop(1, 0, Loc(1, 0), None, 0, 0, 0)  # hipMemAllocationTypePinned, hipMemLocationTypeDevice, device 0
+    gran = C.c_size_t(0)
+    if hip.hipMemGetAllocationGranularity(C.byref(gran), C.byref(prop), 0) != 0 or gran.value == 0:
+        pytest.skip("virtual memory management is not available on this device")
+    k = 15
+    n = 1 << k
+    while n * 64 <= gran.value:  # the bases must span two chunks
+        k, n = k + 1, n << 1
+    chunk = ((n * 64 // 2 + gran.value - 1) // gran.value) * gran.value
+    va = C.c_void_p()
+    assert hip.hipMemAddressReserve(C.byref(va), C.c_size_t(2 * chunk), C.c_size_t(0), None, C.c_ulonglong(0)) == 0
+    handles = []
+    try:
+        for j in range(2):
+            h = C.c_void_p()
+            assert hip.hipMemCreate(C.byref(h), C.c_size_t(chunk), C.byref(prop), C.c_ulonglong(0)) == 0
+            handles.append(h)
+            assert hip.hipMemMap(C.c_void_p(va.value + j * chunk), C.c_size_t(chunk), C.c_size_t(0), h, C.c_ulonglong(0)) == 0
+        acc = Access(Loc(1, 0), 3)  # hipMemAccessFlagsProtReadWrite
+        assert hip.hipMemSetAccess(va, C.c_size_t(2 * chunk), C.byref(acc), C.c_size_t(1)) == 0
+        lib = ffi.load()
+        ds, dr = DeviceBuffer(n * 32), DeviceBuffer(96)
+        ffi.check(lib.panda_gen_bases(0, 0x7A7A, 0, n, va, NULL_STREAM), "gen")
+        ffi.check(lib.panda_gen_scalars(0, 0x7A7B, 0, n, ds.ptr, NULL_STREAM), "gen")
+        cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, va, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+        ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        assert (po.to_affine(0, dr.to_host()) == po.expected_from_linearity(0, 0x7A7A, ds.to_host().reshape(n, 8))).all()
+        ds.free()
+        dr.free()
+    finally:
+        hip.hipDeviceSynchronize()
+        for j, h in enumerate(handles):
+            hip.hipMemUnmap(C.c_void_p(va.value + j * chunk), C.c_size_t(chunk))
+            hip.hipMemRelease(h)
+        hip.hipMemAddressFree(va, C.c_size_t(2 * chunk))
+
+
 def test_msm_phase_timers(gm):
     n = 1 << 12
     pgm.panda_msm_bn254_gpu(gm, po.gen_scalars(po.F_BN254_FR, 1, n), po.gen_bases(0, 2, n))
