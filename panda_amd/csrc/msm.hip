@@ -376,16 +376,25 @@ namespace panda {
 
 hipError_t msm_hash_wire(const void *d_buf, size_t bytes, hipStream_t s, uint64_t *hash)
 {
+    // the workgroups add into a word of DEVICE memory (atomics on host memory would need PCIe atomics, which not every platform
+    // routes); it is copied into the pinned mailbox behind the kernel
     uint32_t *mail = nullptr;
     PANDA_TRY(thread_mailbox(&mail));
-    unsigned long long *h = reinterpret_cast<unsigned long long *>(mail + 32); // pinned host memory the kernel adds into directly
-    *h = 0;
+    unsigned long long *h_sum = reinterpret_cast<unsigned long long *>(mail + 32);
+    unsigned long long *d_sum = nullptr;
+    PANDA_TRY(hipMalloc((void **)&d_sum, 8));
+    hipError_t e = hipMemsetAsync(d_sum, 0, 8, s);
     const u64 units = bytes / 16;
     const unsigned blocks = (unsigned)std::min<u64>((units + 255) / 256, 4096);
-    if (units) hipLaunchKernelGGL(k_hash_wire, dim3(blocks), dim3(256), 0, s, (const uint4 *)d_buf, units, h);
-    PANDA_TRY(hipGetLastError());
-    PANDA_TRY(hipStreamSynchronize(s));
-    *hash = *h;
+    if (e == hipSuccess && units) {
+        hipLaunchKernelGGL(k_hash_wire, dim3(blocks), dim3(256), 0, s, (const uint4 *)d_buf, units, d_sum);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_sum, d_sum, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_sum);
+    if (e != hipSuccess) return e;
+    *hash = *h_sum;
     return hipSuccess;
 }
 

@@ -23,7 +23,7 @@
 //   msm_sort.hip      scalars -> signed window digits -> per-bucket lists of base indices (two or three LDS-staged sort levels)
 //   k_accumulate      flat chunks of K entries: acc += +/- base   (the hot kernel)
 //   k_fixup           merge bucket pieces that straddle chunks
-//   k_sum_lines / k_weighted_finish
+//   k_sum_lines / k_weighted_slots / k_slot_total
 //                     weighted sum of the group sums -> one point per list
 //   host              Horner over the W window sums (as the reference does, msm_cuda.cuh:738-743) -- none with precomputed
 //                     tables, whose single list already carries the 2^lo[k] factors -- and output conversion
@@ -445,14 +445,12 @@ constexpr unsigned LONG_BLOCKS = 256; // workgroups per window that serve the qu
 // defined -- and every non-empty bucket is added into `total`, the running sum over the ranges, here instead of in a pass of its own.
 template <class F, bool MERGE>
 __global__ void __launch_bounds__(256) k_fixup(const u32 *__restrict__ off, const u32 *__restrict__ parts, u32 *__restrict__ bucket_acc, u32 *__restrict__ total,
-                                               unsigned NB, unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap,
-                                               u32 *__restrict__ tickets)
+                                               unsigned NB, unsigned K, unsigned chunks, u32 *__restrict__ long_count, u32 *__restrict__ long_list, unsigned long_cap)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
     const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
-    if (b == 0) tickets[w] = 0; // k_weighted_finish, which runs behind every fix-up of the call, counts its finished workgroups here
     const u32 *ow = off + (u64)w * (NB + 1);
     const u32 s = ow[b], e = ow[b + 1];
     Xyzz<F> acc, q;
@@ -539,9 +537,9 @@ __global__ void __launch_bounds__(256) k_fixup_long(const u32 *__restrict__ part
 //     sum_b (b + 1) B_b  =  sum_hi R_hi  +  cols * sum_hi hi * R_hi  +  sum_lo lo * C_lo,     R_hi = sum_lo B_{hi,lo},  C_lo = sum_hi B_{hi,lo}:
 //   k_sum_lines        row sums and column sums are PLAIN sums, two additions per bucket in all and no dependent chain longer than a
 //                      line; one wave per line (or per segment of a column, when columns are longer than rows).
-//   k_weighted_finish  the two short weighted sums are taken bit by bit: slot 1+j adds up the R_hi (C_lo) whose index has bit j set
-//                      and is doubled j + b (j) times, slot 0 adds up all R_hi; the last workgroup of a list to finish adds the
-//                      list's slots up.  No scalar multiplications anywhere.
+//   k_weighted_slots   the two short weighted sums are taken bit by bit: slot 1+j adds up the R_hi (C_lo) whose index has bit j set
+//                      and is doubled j + b (j) times, slot 0 adds up all R_hi;  k_slot_total adds the list's slots up and, with
+//                      tables, writes the result in wire form.  No scalar multiplications anywhere.
 // (Rounds 1-3 first took running sums over groups of 4-8 buckets -- S_g, T_g, two additions per bucket as well -- and split the GROUP
 // index: one more kernel and 8-16 more dependent additions in front of the same trees.)
 // Everything here is a tree of dependent additions on a few waves: its time is (levels) x (latency of one addition), whatever the
@@ -615,17 +613,13 @@ __global__ void __launch_bounds__(64) k_sum_lines(const u32 *__restrict__ bucket
 // workgroup (slot, list, part), one wave.  slot 0: sum of the R_hi;  slot 1+j (j < a): the R_hi with bit j of hi set, doubled j + b
 // times;  slot 1+a+j (j < b): the column (segment) sums with bit j of lo set, doubled j times (rows = 2^a, cols = 2^b).  A slot's
 // entries are shared out over `parts` workgroups, each of which doubles its own partial sum (2^k (x + y) = 2^k x + 2^k y: the doublings
-// of the parts run side by side).  The workgroup that finishes last (tickets[list]) adds the list's slots * parts partial sums up
-// into win[list] -- as an XYZZ point (emit = 0: the host still has a Horner step to do over the lists), or, for a single list whose
-// sum IS the result, in the wire format of the C ABI: Jacobian X || Y || Z (emit = 1) or homogeneous (emit = 2).  `win` may be device
-// memory or pinned host memory.
+// of the parts run side by side).  k_slot_total adds the list's slots * parts partial sums up.
 template <class F>
-__global__ void __launch_bounds__(64) k_weighted_finish(const u32 *__restrict__ inR, const u32 *__restrict__ inC, u32 *slot_out, u32 *__restrict__ win, u32 *tickets,
-                                                        unsigned a, unsigned b, unsigned csplit, unsigned emit)
+__global__ void __launch_bounds__(64) k_weighted_slots(const u32 *__restrict__ inR, const u32 *__restrict__ inC, u32 *__restrict__ slot_out, unsigned a, unsigned b,
+                                                       unsigned csplit)
 {
     constexpr int PW = 4 * F::N;
     __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
-    __shared__ u32 ticket;
     const unsigned slot = blockIdx.x, list = blockIdx.y, part = blockIdx.z, parts = gridDim.z, lane = threadIdx.x, role = lane & 3u;
     const unsigned rows = 1u << a, cols = 1u << b, slots = 1 + a + b, partials = slots * parts;
     Xyzz<F> acc, q;
@@ -664,12 +658,20 @@ __global__ void __launch_bounds__(64) k_weighted_finish(const u32 *__restrict__ 
         }
         if (lane == 0) store_xyzz<F>(slot_out + ((u64)list * partials + slot * parts + part) * PW, acc);
     }
-    __threadfence();
-    __syncthreads();
-    if (lane == 0) ticket = atomicAdd(&tickets[list], 1u);
-    __syncthreads();
-    if (ticket != partials - 1) return; // uniform over the workgroup
-    __threadfence(); // the other workgroups' partial sums are visible from here on
+}
+
+// workgroup `list`, one wave: the list's slots * parts partial sums -> win[list] -- as an XYZZ point (emit = 0: the host still has a
+// Horner step to do over the lists), or, for a single list whose sum IS the result, in the wire format of the C ABI: Jacobian
+// X || Y || Z (emit = 1) or homogeneous (emit = 2).  `win` may be device memory or pinned host memory.
+// (A kernel of its own rather than the last-to-finish workgroup of k_weighted_slots: the device-scope fences such a hand-off needs
+// write the XCD's L2 back in every workgroup -- profiles/r04_msm_small_sizes.txt -- and cost more than the launch.)
+template <class F>
+__global__ void __launch_bounds__(64) k_slot_total(const u32 *__restrict__ slot_out, u32 *__restrict__ win, unsigned partials, unsigned emit)
+{
+    constexpr int PW = 4 * F::N;
+    __shared__ __attribute__((aligned(16))) u32 lds[64 * PW];
+    const unsigned list = blockIdx.x, lane = threadIdx.x;
+    Xyzz<F> acc, q;
     xyzz_set_identity(acc);
 #pragma unroll 1
     for (unsigned i = lane; i < partials; i += 64) {
@@ -804,7 +806,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const unsigned rc_b = (c - 1) / 2, rc_a = (c - 1) - rc_b;
     const unsigned rc_rows = 1u << rc_a, rc_cols = 1u << rc_b, rc_csplit = rc_a > rc_b ? 2u : 1u;
     const unsigned slots = 1 + rc_a + rc_b; // slot 0: all rows; then one per bit of hi and of lo
-    // workgroups per slot of k_weighted_finish: at most four entries per lane (2^21 buckets: 1024 of the 2048 row sums per slot)
+    // workgroups per slot of k_weighted_slots: at most four entries per lane (2^21 buckets: 1024 of the 2048 row sums per slot)
     const unsigned rc_parts = std::max(1u, std::max(rc_rows, rc_cols * rc_csplit) / 512u);
 
     // ---- scratch
@@ -820,7 +822,6 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
     const size_t sz_l1 = panda::align256((size_t)lists * (rc_rows + rc_cols * rc_csplit) * PW * 4);
     const size_t sz_win = 256; // the stale-registration flag (device copy: k_accumulate reads it)
-    const size_t sz_tickets = panda::align256((size_t)lists * 4);
     const size_t sz_slots = panda::align256((size_t)lists * slots * rc_parts * PW * 4);
     const size_t sz_lcount = panda::align256((size_t)lists * 4);
     panda::Arena &arena = panda::thread_arena();
@@ -828,7 +829,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     // scratch, pieces and range buckets, so that range r+1 is sorted (LDS / HBM work) while range r is still being accumulated
     // (vector issue); the fix-ups, which all add into the one total, are chained by events.
     const unsigned lanes = nranges > 1 ? 2u : 1u;
-    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + sz_l1 + sz_win + sz_slots + sz_tickets + 8192));
+    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + sz_l1 + sz_win + sz_slots + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
     u32 *d_bacc_range[2] = {d_bacc, d_bacc}, *d_parts_l[2] = {nullptr, nullptr}, *d_lcount_l[2] = {nullptr, nullptr}, *d_llist_l[2] = {nullptr, nullptr};
@@ -842,8 +843,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_stale = (u32 *)arena.take(sz_win);
     u32 *d_slots = (u32 *)arena.take(sz_slots);
-    u32 *d_tickets = (u32 *)arena.take(sz_tickets);
-    if (!d_bases || !d_bacc || !d_l1 || !d_stale || !d_slots || !d_tickets) return hipErrorOutOfMemory;
+    if (!d_bases || !d_bacc || !d_l1 || !d_stale || !d_slots) return hipErrorOutOfMemory;
     // What the call hands back to this host thread travels through pinned host memory the kernels write into directly: word 0 is set
     // by the digits kernel when the registered buffer has changed, the window sums (or, with tables, the finished result) land behind it.
     u32 *mail = nullptr;
@@ -970,11 +970,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         constexpr unsigned fx_block = 256;
         if (r == 0)
             hipLaunchKernelGGL((k_fixup<Fq, false>), dim3((NB + fx_block - 1) / fx_block, lists), dim3(fx_block), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
-                               d_llist, g.long_cap, d_tickets);
+                               d_llist, g.long_cap);
         else {
             if (lanes > 1) PANDA_TRY(hipStreamWaitEvent(ls, phase_events.fixed[r - 1], 0)); // the total is complete up to the previous range
             hipLaunchKernelGGL((k_fixup<Fq, true>), dim3((NB + fx_block - 1) / fx_block, lists), dim3(fx_block), 0, ls, sorted.off, d_parts, target, d_bacc, NB, g.K, g.chunks, d_lcount,
-                               d_llist, g.long_cap, d_tickets);
+                               d_llist, g.long_cap);
         }
         hipLaunchKernelGGL(k_fixup_long<Fq>, dim3(LONG_BLOCKS, lists), dim3(256), 0, ls, d_parts, d_bacc, r == 0 ? 0u : 1u, NB, g.chunks, d_lcount, d_llist, g.long_cap);
         if (lanes > 1) PANDA_TRY(hipEventRecord(phase_events.fixed[r], ls));
@@ -986,8 +986,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         u32 *d_rows = d_l1, *d_cols = d_l1 + (size_t)lists * rc_rows * PW;
         hipLaunchKernelGGL(k_sum_lines<Fq>, dim3(rc_rows + rc_cols * rc_csplit, lists), dim3(64), 0, stream, d_bacc, d_rows, d_cols, rc_rows, rc_cols, rc_csplit);
         const unsigned emit = tabled ? (cfg.msm_result_coordinate_type == PROJECTIVE ? 2u : 1u) : 0u;
-        hipLaunchKernelGGL(k_weighted_finish<Fq>, dim3(slots, lists, rc_parts), dim3(64), 0, stream, d_rows, d_cols, d_slots, res_dev ? res_dev : h_win, d_tickets, rc_a,
-                           rc_b, rc_csplit, emit);
+        hipLaunchKernelGGL(k_weighted_slots<Fq>, dim3(slots, lists, rc_parts), dim3(64), 0, stream, d_rows, d_cols, d_slots, rc_a, rc_b, rc_csplit);
+        hipLaunchKernelGGL(k_slot_total<Fq>, dim3(lists), dim3(64), 0, stream, d_slots, res_dev ? res_dev : h_win, slots * rc_parts, emit);
     }
     PANDA_TRY(mark(6));
     PANDA_TRY(hipGetLastError());
