@@ -779,9 +779,12 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     if (N <= K3_CAP) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
         // (the cell's buckets are adjacent in the output)
+        // ONE LDS atomic per entry: the count's return value is the entry's rank within its bucket, kept (with the bucket's 7 bits) in a
+        // register until the offsets are known -- the ranking pass then needs no second atomic.  With 128 counters under 64 lanes the
+        // atomics are the merge's bottleneck (two per entry: 1.00 ms at 2^24; one: see profiles/r04_msm_small_sizes.txt)
         u32 word[K3_PER];
-        unsigned char lo[K3_PER];
-        unsigned k = 0; // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
+        u32 where[K3_PER]; // rank << 7 | bucket
+        unsigned k = 0;    // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
             const u32 p = tid + j * K3_THREADS;
@@ -789,8 +792,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
                 while (p >= vstart[k + 1]) k++;
                 const u32 v = p2[rbegin[k] + (p - vstart[k])];
                 word[j] = final_word(v, k);
-                lo[j] = (unsigned char)(v >> shift);
-                atomicAdd(&cnt[v >> shift], 1u);
+                const u32 b = v >> shift;
+                where[j] = (atomicAdd(&cnt[b], 1u) << 7) | b;
             }
         }
         __syncthreads();
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
             const u32 p = tid + j * K3_THREADS;
-            if (p < N) outbuf[atomicAdd(&cur[lo[j]], 1u)] = word[j];
+            if (p < N) outbuf[cur[where[j] & 127u] + (where[j] >> 7)] = word[j];
         }
         __syncthreads();
         for (u32 p = tid; p < N; p += K3_THREADS) sw[out_rel + p] = outbuf[p];
