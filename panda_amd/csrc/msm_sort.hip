@@ -776,6 +776,11 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         return ((v & id_mask) + g.row0 + (table_shift < 32 ? (k << table_shift) : 0u)) | (((v >> g.log_n) & 1u) << 31);
     };
 
+    if (N == 0) { // an empty cell: its buckets all start where the cell does
+        if (tid < L) ow[((u64)q << g.b3) + tid] = out_rel;
+        if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel;
+        return;
+    }
     if (N <= K3_CAP) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
         // (the cell's buckets are adjacent in the output)
@@ -783,15 +788,23 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         // register until the offsets are known -- the ranking pass then needs no second atomic.  With 128 counters under 64 lanes the
         // atomics are the merge's bottleneck (two per entry: 1.00 ms at 2^24; one: see profiles/r04_msm_small_sizes.txt)
         u32 word[K3_PER];
-        u32 where[K3_PER]; // rank << 7 | bucket
+        u32 where[K3_PER]; // run of the entry, then rank << 7 | bucket
         unsigned k = 0;    // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
+        // all of a thread's loads go out before the first word is looked at: with the count in the same loop every iteration waited
+        // for its own HBM round trip (a dozen in sequence per workgroup)
+#pragma unroll
+        for (unsigned j = 0; j < K3_PER; j++) {
+            const u32 p = min(tid + j * K3_THREADS, N - 1); // positions past the end re-read the last entry and are dropped below (N > 0 here)
+            while (p >= vstart[k + 1]) k++;
+            where[j] = k;
+            word[j] = p2[rbegin[k] + (p - vstart[k])];
+        }
 #pragma unroll
         for (unsigned j = 0; j < K3_PER; j++) {
             const u32 p = tid + j * K3_THREADS;
             if (p < N) {
-                while (p >= vstart[k + 1]) k++;
-                const u32 v = p2[rbegin[k] + (p - vstart[k])];
-                word[j] = final_word(v, k);
+                const u32 v = word[j];
+                word[j] = final_word(v, where[j]);
                 const u32 b = v >> shift;
                 where[j] = (atomicAdd(&cnt[b], 1u) << 7) | b;
             }
