@@ -233,15 +233,20 @@ class MsmProblem:
     def all_phases(self, reps: int = 3):
         """Per-phase device times from `reps` extra, untimed calls with every phase timer on (the timed steps record the
         accumulate kernel and the call's total only: each further event costs a few microseconds of idle GPU)."""
+        return self.timed_phases(2, reps)
+
+    def timed_phases(self, level: int, reps: int = 3):
+        """mean phase times of `reps` extra, untimed calls at phase-timer level `level` (1: the total and k_accumulate); the library's
+        default -- what a timed step runs at unless it says otherwise -- records no device timers at all"""
         lib = self.ctx.lib
-        lib.panda_msm_set_phase_timing(2)
+        lib.panda_msm_set_phase_timing(level)
         try:
             rows = []
             for _ in range(reps):
                 self.execute()
                 rows.append(self.phases())
         finally:
-            lib.panda_msm_set_phase_timing(1)
+            lib.panda_msm_set_phase_timing(0)
         return [sum(r[i] for r in rows) / len(rows) for i in range(8)]
 
     def release(self):
@@ -261,6 +266,7 @@ def single_process(args) -> dict:
     from panda_amd import multi_gpu
 
     lib = ffi.load()
+    lib.panda_msm_set_phase_timing(1)  # per-rank k_accumulate / device times are part of this mode's line
     G = args.gpus
     devices = [0] * G if args.loopback else list(range(G))
     transport = ffi.MULTI_LOOPBACK if args.loopback else ffi.MULTI_RCCL
@@ -424,7 +430,9 @@ def main():
             acc_ms.append(prob.phases())
         prob.exchange()
 
+    lib.panda_msm_set_phase_timing(1)  # the headline's roofline wants k_accumulate timed inside the timed steps (HIP events on its launch stream)
     dt = ctx.timed(step, args.warmup, args.steps)
+    lib.panda_msm_set_phase_timing(0)
 
     out = None
     if rank == 0:
@@ -571,7 +579,7 @@ def config4(ctx: Ctx, total_log_n: int) -> dict:
         prob.exchange()
 
     dt = ctx.timed(step, 1, steps)
-    ph = prob.phases()
+    ph = prob.timed_phases(1, 1)
     res = {"metric": f"MSM points/s (BN254, 2^{total_log_n} in total)", "value": (1 << total_log_n) * steps / dt, "unit": "points/s",
            "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": ctx.world, "scaling": "strong", "log_points_per_gpu": log_per,
            "workload": f"BN254 MSM 2^{total_log_n}, {ctx.world} base range(s) of 2^{log_per} points, all-gather of 96 B partials + combine",
@@ -587,8 +595,8 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
     for label in ("with_tables", "registered_only"):
         if label == "registered_only":
             prob.register(False)
-        dt = ctx.timed(lambda _t: prob.execute(), 2, steps) / steps
-        ph = prob.phases()
+        dt = ctx.timed(lambda _t: prob.execute(), 2, steps) / steps  # no device timers inside these steps (the library's default)
+        ph = prob.timed_phases(1, 3)                                 # k_accumulate and the device total: three separate calls
         res[label] = {"value": prob.n / dt, "ms_per_step": dt * 1e3, "bases": prob.mode, "k_accumulate_ms": ph[3], "device_ms": ph[7],
                       "roofline_frac_hbm": BYTES_PER_POINT[curve] * prob.n / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if curve in MADS_PER_ADDITION and ph[3] > 0:
@@ -618,7 +626,7 @@ def without_tables(ctx: Ctx, prob: MsmProblem, steps: int) -> dict:
     dt = ctx.timed(lambda _t: prob.execute(), 1, steps) / steps
     wb, wn = C.c_uint(0), C.c_uint(0)
     ctx.lib.panda_msm_plain_window_plan(prob.curve, prob.log_n, C.byref(wb), C.byref(wn))
-    res = {"ms_per_step": dt * 1e3, "value": prob.n / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": prob.phases()[3],
+    res = {"ms_per_step": dt * 1e3, "value": prob.n / dt, "unit": "points/s", "steps": steps, "k_accumulate_ms": prob.timed_phases(1, 2)[3],
            "windows": f"{wn.value} windows of {wb.value} bits"}
     ctx.ffi.check(ctx.lib.panda_msm_unregister_bases(prob.bases.data_ptr()), "unregister_bases")
     prob.registered = False

@@ -199,8 +199,8 @@ panda_error panda_msm_set_window_bits(unsigned window_bits);
 panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned *window_bits, unsigned *windows);
 /* sorted entries per thread of the bucket-accumulation kernel, for experiments: 0 = built-in policy (rounded up to a multiple of 4) */
 panda_error panda_msm_set_chunk_entries(unsigned entries);
-/* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = the call's total only,
- * 1 = total + the bucket-accumulation kernel (default), 2 = every phase.  Phases that were not timed read 0 in panda_msm_last_phase_ms. */
+/* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = none (default),
+ * 1 = the call's total + the bucket-accumulation kernel, 2 = every phase.  Phases that were not timed read 0 in panda_msm_last_phase_ms. */
 panda_error panda_msm_set_phase_timing(unsigned level);
 /* per-phase device times of the last MSM on this thread, milliseconds; names via panda_msm_phase_name */
 #define PANDA_MSM_PHASES 8

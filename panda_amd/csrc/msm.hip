@@ -204,7 +204,7 @@ size_t forget_if(Pred pred)
 
 std::atomic<unsigned> g_window_override{0};
 std::atomic<unsigned> g_chunk{0};
-std::atomic<unsigned> g_phase_timing{1};
+std::atomic<unsigned> g_phase_timing{0};
 std::atomic<unsigned> g_paranoid{0};
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",

@@ -55,7 +55,7 @@ hipError_t msm_hash_wire(const void *d_buf, size_t bytes, hipStream_t s, uint64_
 struct MsmTuning {
     unsigned window_bits;  // plain-mode window width (already resolved by the policy)
     unsigned chunk;        // sorted entries per k_accumulate thread, 0 = built-in
-    unsigned timing;       // 0: total device time only; 1: + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
+    unsigned timing;       // 0: no device timers at all; 1: the call's total + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -910,7 +910,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     // which of the eight events a call records: an event between two kernels keeps the GPU idle for ~6 us (rocprofv3 timeline of a
     // 2^20-point call, profiles/r04_*), so only the level the caller asked for is paid for
     const unsigned timing = tuning.timing;
-    auto wanted = [&](int i) { return i == 0 || i >= 6 || (timing >= 1 && (i == 3 || i == 4)) || timing >= 2; };
+    auto wanted = [&](int i) { return timing >= 2 || (timing == 1 && (i == 0 || i == 3 || i == 4 || i >= 6)); };
     auto mark = [&](int i) { return wanted(i) ? hipEventRecord(ev[i], stream) : hipSuccess; };
 
     // upload of range r on the copy stream (a pageable source makes the call block until the range is staged, a pinned one returns at once)
@@ -1030,10 +1030,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         phase_ms[i] = 0;
         if (wanted(i) && wanted(i + 1) && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) phase_ms[i] = ms;
     }
-    (void)hipEventElapsedTime(&ms, ev[6], ev[7]);
-    phase_ms[6] = ms;
-    (void)hipEventElapsedTime(&ms, ev[0], ev[6]);
-    phase_ms[7] = ms;
+    phase_ms[6] = phase_ms[7] = 0;
+    if (wanted(6) && wanted(7) && hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) phase_ms[6] = ms;
+    if (wanted(0) && wanted(6) && hipEventElapsedTime(&ms, ev[0], ev[6]) == hipSuccess) phase_ms[7] = ms;
     return hipSuccess;
 }
 

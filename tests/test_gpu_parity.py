@@ -384,12 +384,25 @@ def test_msm_bases_in_a_virtual_memory_mapping(gm):
 
 
 def test_msm_phase_timers(gm):
+    """device timers are off by default (an event between two kernels costs GPU idle time); level 1 times the total and k_accumulate,
+    level 2 every phase"""
     n = 1 << 12
-    pgm.panda_msm_bn254_gpu(gm, po.gen_scalars(po.F_BN254_FR, 1, n), po.gen_bases(0, 2, n))
+    lib = ffi.load()
     ms = (C.c_float * 8)()
-    ffi.check(ffi.load().panda_msm_last_phase_ms(ms), "phase")
-    assert all(v >= 0 for v in ms) and ms[7] > 0
-    assert ffi.load().panda_msm_phase_name(3) == b"accumulate"
+    seen = {}
+    try:
+        for level in (0, 1, 2):
+            ffi.check(lib.panda_msm_set_phase_timing(level), "cfg")
+            pgm.panda_msm_bn254_gpu(gm, po.gen_scalars(po.F_BN254_FR, 1, n), po.gen_bases(0, 2, n))
+            ffi.check(lib.panda_msm_last_phase_ms(ms), "phase")
+            seen[level] = list(ms)
+    finally:
+        lib.panda_msm_set_phase_timing(0)
+    assert all(v == 0 for v in seen[0])
+    assert seen[1][7] > 0 and seen[1][3] > 0 and seen[1][1] == 0
+    assert all(v >= 0 for v in seen[2]) and seen[2][7] > 0 and seen[2][1] > 0
+    assert lib.panda_msm_set_phase_timing(3) != 0
+    assert lib.panda_msm_phase_name(3) == b"accumulate"
 
 
 # ------------------------------------------------------------------ NTT
@@ -600,7 +613,12 @@ def test_c_abi_multi_gpu_msm(gm, ranks, transport):
         # each rank's buffer holds the Jacobian partial of its own range
         r = ranks - 1
         assert (po.to_affine(0, results[r].to_host()) == po.expected_from_linearity(0, seed_b, scalars[r * per:(r + 1) * per], first=r * per)).all()
-        assert mg.phases(r)[7] > 0
+        lib.panda_msm_set_phase_timing(1)
+        try:
+            mg.msm(cfgs)
+            assert mg.phases(r)[7] > 0
+        finally:
+            lib.panda_msm_set_phase_timing(0)
         bad = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), None, ds.ptr, results[0].ptr, 4, pgm.JACOBIAN)] * ranks
         with pytest.raises(ffi.PandaGpuError):
             mg.msm(bad)  # a failing rank fails the call, the handle stays usable

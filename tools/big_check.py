@@ -18,6 +18,7 @@ from panda_amd import gpu_manager as pgm  # noqa: E402
 
 def run(gm, cid, k, check=True):
     lib = ffi.load()
+    lib.panda_msm_set_phase_timing(2)
     n = 1 << k
     lc = po.LC_Q[cid]
     db, ds, dr = DeviceBuffer(n * 2 * lc * 4), DeviceBuffer(n * 32), DeviceBuffer(3 * lc * 4)

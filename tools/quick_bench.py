@@ -18,6 +18,7 @@ def main():
     ks = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "16,20,22,24".split(","))]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     lib = ffi.load()
+    lib.panda_msm_set_phase_timing(2)
     gm = pgm.PandaGpuManager(0)
     names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
     for k in ks:

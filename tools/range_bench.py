@@ -16,6 +16,7 @@ if os.environ.get("PANDA_LIB"):  # timing experiments: another build of the libr
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n = 1 << log_n
 lib = ffi.load()
+    lib.panda_msm_set_phase_timing(2)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 ps = ffi.PandaStream(stream.cuda_stream)
