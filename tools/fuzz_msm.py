@@ -45,9 +45,11 @@ def main():
         bases = po.gen_bases(cid, seed, n)
         want = po.expected_from_linearity(cid, seed, scalars)
         mode = int(rng.integers(0, 3))
+        if mode == 1:  # registered bases, plain windows: forced widths incl. the three-level sort with a list per window
+            lib.panda_msm_set_window_bits(int(rng.choice([0, 12, 16, 17, 19, 20])))
         wb = int(rng.choice([0, 0, 8, 10, 12, 14, 16, 18, 20, 22]))
         if mode == 0:
-            lib.panda_msm_set_window_bits(int(rng.choice([0, 0, 4, 5, 7, 9, 11, 13, 16])))
+            lib.panda_msm_set_window_bits(int(rng.choice([0, 0, 4, 5, 7, 9, 11, 13, 16, 17, 18, 19, 20])))
             out = pgm.panda_msm_bn254_gpu(gm, scalars, bases, curve=cid)
             lib.panda_msm_set_window_bits(0)
         else:
@@ -61,6 +63,7 @@ def main():
                 continue
             out = pgm.panda_msm_bn254_gpu_with_cached_bases(gm, scalars, idx, curve=cid)
             lib.panda_msm_unregister_bases(gm.d_bases[idx])
+            lib.panda_msm_set_window_bits(0)
         got = po.to_affine(cid, out.view(np.uint32))
         if not (got == want).all():
             bad += 1
