@@ -726,11 +726,13 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
     fwd, fwd_wall = timed(lib.panda_ntt_execute_bn254_v1)
     inv, inv_wall = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
+    passes, bits = C.c_uint(0), (C.c_uint * 4)()
+    ffi.check(lib.panda_ntt_pass_plan(log_n, C.byref(passes), bits), "ntt_plan")
     del a, b
     torch.cuda.empty_cache()
     return {"value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3, "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv,
             "forward_plus_inverse_ms": (fwd + inv) * 1e3, "forward_plus_inverse_elements_per_s": n / (fwd + inv),
-            "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3, "passes": -(-log_n // 8),
+            "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3, "passes": passes.value, "radix_bits": [int(b) for b in bits if b],
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 

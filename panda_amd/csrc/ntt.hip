@@ -31,6 +31,7 @@
 
 #include "fe29.h"
 #include "ntt_radix8.h"
+#include "ntt_radix9.h"
 #include "panda_internal.h"
 
 using namespace panda29;
@@ -42,13 +43,13 @@ constexpr int TW_STRIDE = 12;   // table entries padded to 48 B for 16-byte load
 constexpr int TILE = 1024;      // elements per workgroup
 
 struct PowBase {
-    u32 pw[16][NL]; // base^(2^j), canonical internal form
+    u32 pw[20][NL]; // base^(2^j), canonical internal form
     u32 scale[NL];  // optional factor folded into every entry
     int has_scale;
 };
 
 // out[t] = base^e(t) (* scale), canonical, t < count.  e(t) = t, or, for the two-dimensional tables of the wide inter-pass
-// twiddles (rows_deg != 0), e(t) = (t >> rows_deg) * (t & (2^rows_deg - 1)): row a holds base^(a i), i < 2^rows_deg.  e < 2^16.
+// twiddles (rows_deg != 0), e(t) = (t >> rows_deg) * (t & (2^rows_deg - 1)): row a holds base^(a i), i < 2^rows_deg.  e < 2^20.
 template <class Fr>
 __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, unsigned rows_deg, u32 *__restrict__ out)
 {
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u
     } else
         fe_one(acc);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < 20; j++) {
         if ((t >> j) & 1) {
 #pragma unroll
             for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) k_pow_table2(PowBase pb, unsigned count, 
     } else
         fe_one(acc);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < 20; j++) {
         if ((t >> j) & 1) {
 #pragma unroll
             for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
@@ -404,12 +405,72 @@ bool g_omega_set = false;
 const size_t SZ_TA = panda::align256((size_t)(1u << 16) * panda_ntt8::TW2_STRIDE * 4);
 const size_t SZ_TB = panda::align256((size_t)(1u << 16) * panda_ntt8::TW2_STRIDE * 4);
 const size_t SZ_PQ = panda::align256((size_t)128 * panda_ntt8::TW2_STRIDE * 4);
+// plans with a radix-512 pass (k_ntt_pass9): inter-pass tables of up to 2^18 entries, 256 butterfly twiddles
+const size_t SZ_T18 = panda::align256((size_t)(1u << 18) * panda_ntt8::TW2_STRIDE * 4);
+const size_t SZ_PQ9 = panda::align256((size_t)256 * panda_ntt8::TW2_STRIDE * 4);
+
+// The radices of a transform's passes.  The reference's loop (fft.cu:171-216) takes eight bits per pass and whatever is left in the
+// last one; sizes whose bit count leaves a short last pass behind three (two) full ones run one pass less with radix-512 passes in
+// front: 2^17 = 9 + 8, 2^18 = 9 + 9, 2^25 = 9 + 8 + 8, 2^26 = 9 + 9 + 8, 2^27 = 9 + 9 + 9.  The bit-reversed orderings keep the
+// eight-bit plan (their address maps live in k_ntt_pass8).  *flag = passes & 1 either way: callers read it (unit.rs:458-470).
+struct PassPlan {
+    unsigned count = 0;
+    unsigned d[8] = {0};
+    bool wide = false; // contains a radix-512 pass
+};
+
+PassPlan plan_passes(unsigned log_n, bool bit_reversed)
+{
+    PassPlan pl;
+    unsigned nines = 0;
+    if (!bit_reversed) {
+        switch (log_n) {
+        case 17: case 25: nines = 1; break;
+        case 18: case 26: nines = 2; break;
+        case 27: nines = 3; break;
+        default: break;
+        }
+    }
+    unsigned left = log_n;
+    for (unsigned j = 0; j < nines; j++) {
+        pl.d[pl.count++] = 9;
+        left -= 9;
+    }
+    pl.wide = nines != 0;
+    while (left) {
+        const unsigned deg = left < 8 ? left : 8;
+        pl.d[pl.count++] = deg;
+        left -= deg;
+    }
+    return pl;
+}
+
+struct PassTables {
+    size_t ta, tb, pq;
+};
+PassTables pass_tables(const PassPlan &pl, unsigned j)
+{
+    if (!pl.wide) return PassTables{SZ_TA, SZ_TB, SZ_PQ};
+    const bool last = j + 1 == pl.count;
+    return PassTables{last ? 256 : SZ_T18, last ? 256 : SZ_T18, SZ_PQ9};
+}
+// bytes ntt_passes carves out of its arena for a transform of 2^log_n points
+size_t passes_table_bytes(unsigned log_n, bool bit_reversed = false)
+{
+    const PassPlan pl = plan_passes(log_n, bit_reversed);
+    size_t total = 0;
+    for (unsigned j = 0; j < pl.count; j++) {
+        const PassTables t = pass_tables(pl, j);
+        total += t.ta + t.tb + t.pq + 3 * 256;
+    }
+    return total;
+}
 
 template <class Fr>
 void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
 {
     Fe<Fr> cur = base;
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < 20; j++) {
         Fe<Fr> c = cur;
         fe_reduce_once(c);
         for (int i = 0; i < NL; i++) pb.pw[j][i] = c.l[i];
@@ -448,6 +509,21 @@ void launch_pass8(bool first, bool last, const panda_ntt8::Pass8Args &a, unsigne
         hipLaunchKernelGGL((k_ntt_pass8<Fr, true, false, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
     else
         hipLaunchKernelGGL((k_ntt_pass8<Fr, false, false, P8_PLANES, P8_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
+}
+
+// radix-512 pass: exchange batches of three limb planes (24 KB + 20 KB of twiddles), three workgroups per CU
+constexpr int P9_PLANES = 3, P9_MINW = 3;
+
+template <class Fr>
+void launch_pass9(bool first, bool last, const panda_ntt8::Pass8Args &a, unsigned tiles, hipStream_t s)
+{
+    using namespace panda_ntt8;
+    if (last)
+        hipLaunchKernelGGL((k_ntt_pass9<Fr, false, true, P9_PLANES, P9_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
+    else if (first)
+        hipLaunchKernelGGL((k_ntt_pass9<Fr, true, false, P9_PLANES, P9_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_ntt_pass9<Fr, false, false, P9_PLANES, P9_MINW>), dim3(tiles), dim3(THREADS), 0, s, a);
 }
 
 // short last pass / size-G slab transforms in registers (radix 2, 4, 8): d_pq holds max(1, 2^(deg-1)) precomputed-quotient entries
@@ -664,21 +740,24 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
-    const unsigned max_deg = log_n < 8 ? log_n : 8; // MAX_LOG2_RADIX, fft.cu:9,177
-    const unsigned total_passes = (log_n + 7) / 8;
-    // Transforms of 2^11 points and more run their radix-256 passes in k_ntt_pass8, which multiplies the twiddle between two passes
-    // onto the OUTPUT of the earlier one; a shorter last pass (k_ntt_pass) then finds it done.  Smaller transforms keep the
-    // twiddle on the input side of k_ntt_pass.
+    const PassPlan pl = plan_passes(log_n, br_in || br_out);
+    const unsigned total_passes = pl.count;
+    // Transforms of 2^11 points and more run their radix-256 / radix-512 passes in k_ntt_pass8 / k_ntt_pass9, which multiply the twiddle
+    // between two passes onto the OUTPUT of the earlier one; a shorter last pass (k_ntt_small) then finds it done.  Smaller transforms
+    // keep the twiddle on the input side of k_ntt_pass.
     const bool regs8 = log_n >= 11;
+    const unsigned cap = pl.wide ? 18 : 16; // log2 of the largest inter-pass table
     while (log_p < log_n) {
-        const unsigned deg = std::min(max_deg, log_n - log_p);
+        const unsigned deg = pl.d[passes];
         const bool last = (passes + 1 == total_passes);
-        u32 *d_ta = (u32 *)arena.take(SZ_TA), *d_tb = (u32 *)arena.take(SZ_TB), *d_pq = (u32 *)arena.take(SZ_PQ);
+        const PassTables sz = pass_tables(pl, passes);
+        u32 *d_ta = (u32 *)arena.take(sz.ta), *d_tb = (u32 *)arena.take(sz.tb), *d_pq = (u32 *)arena.take(sz.pq);
         if (!d_ta || !d_tb || !d_pq) return hipErrorOutOfMemory;
         Fe<Fr> base;
-        if (regs8 && (deg == 8 || (last && deg >= 4))) { // a last pass of radix 16 ... 128 runs as k_ntt_pass8 with its first 8 - deg rounds off
+        if (regs8 && (deg == 9 || deg == 8 || (last && deg >= 4))) { // a last pass of radix 16 ... 128 runs as k_ntt_pass8 with its first 8 - deg rounds off
             panda_ntt8::Pass8Args a{};
-            a.skip = 8 - deg;
+            const unsigned full = deg == 9 ? 9 : 8; // rounds of the kernel that runs this pass
+            a.skip = full - deg;
             a.x = src;
             a.y = dst;
             a.pq = d_pq;
@@ -688,23 +767,23 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             a.lgp = log_p;
             a.br_in = (br_in && passes == 0) ? 1 : 0;
             a.br_out = (br_out && last) ? 1 : 0;
-            const unsigned deg2 = last ? 0 : std::min(8u, log_n - log_p - 8); // radix of the next pass (deg == 8 unless last)
+            const unsigned deg2 = last ? 0 : pl.d[passes + 1]; // radix of the next pass (deg == full unless last)
             if (!last) {
-                // twiddle W^(i2 k2), W = w^(n / 2^(log_p + 8 + deg2)), k2 < 2^(log_p + 8), i2 < 2^deg2; tables of at most 2^16 entries
-                if (log_p + 8 + deg2 <= 16) {
-                    a.ca = log_p + 8;
+                // twiddle W^(i2 k2), W = w^(n / 2^(log_p + deg + deg2)), k2 < 2^(log_p + deg), i2 < 2^deg2; tables of at most 2^cap entries
+                if (log_p + deg + deg2 <= cap) {
+                    a.ca = log_p + deg;
                     a.cb = 0;
                 } else {
-                    a.ca = std::min(log_p, 16 - deg2);
-                    a.cb = log_p + 8 - a.ca;
+                    a.ca = std::min(log_p, cap - deg2);
+                    a.cb = log_p + deg - a.ca;
                 }
-                a.i2_shift = log_n - deg2 - log_p - 8;
+                a.i2_shift = log_n - deg2 - log_p - deg;
             }
             if (build) {
-                fe_pow_u64(base, omega, n >> 8); // butterfly twiddles (w^(n / 256))^t
-                build_table2<Fr>(stream, base, nullptr, 128, d_pq);
+                fe_pow_u64(base, omega, n >> full); // butterfly twiddles (w^(n / 2^full))^t
+                build_table2<Fr>(stream, base, nullptr, 1u << (full - 1), d_pq);
                 if (!last) {
-                    fe_pow_u64(base, omega, n >> (log_p + 8) >> deg2);
+                    fe_pow_u64(base, omega, n >> (log_p + deg) >> deg2);
                     build_table2<Fr>(stream, base, (scale && passes == 0) ? scale : nullptr, 1u << (deg2 + a.ca), d_ta, a.ca);
                     if (a.cb) {
                         Fe<Fr> base_b;
@@ -713,7 +792,10 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
                     }
                 }
             }
-            launch_pass8<Fr>(passes == 0, last, a, (unsigned)(n / panda_ntt8::ELEMS), stream);
+            if (deg == 9)
+                launch_pass9<Fr>(passes == 0, last, a, (unsigned)(n / panda_ntt8::ELEMS), stream);
+            else
+                launch_pass8<Fr>(passes == 0, last, a, (unsigned)(n / panda_ntt8::ELEMS), stream);
         } else if (regs8 && last && deg <= 3) {
             // a short last pass behind k_ntt_pass8 (its twiddle is already on the data): radix 2 / 4 / 8 in registers
             if (build) {
@@ -790,7 +872,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     PANDA_TRY(order_after_null_stream(stream));
     TwiddleCache &tw = g_twiddles[TW_WHOLE];
     u32 key[12];
-    twiddle_key<Fr>(key, log_n, inverse ? 1u : 0u, omega_wire);
+    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | ((br_in || br_out) ? 2u : 0u), omega_wire); // the bit-reversed orderings may run another plan
     PANDA_TRY(tw.settle(stream));
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
@@ -801,7 +883,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
         fe_from_wire(omega, omega_wire);
         if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-        PANDA_TRY(tw.ensure(4 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in || br_out) + 4096));
     } else
         tw.used = 0;
     tw.valid = false;
@@ -908,7 +990,7 @@ hipError_t slab_step1(const panda_ntt_slab_configuration &cfg, bool wait)
     if (!hit) {
         fe_from_wire(omega, (const u32 *)cfg.omega);
         fe_pow_u64(omega_m, omega, (u64)1 << cfg.log_ranks); // root of the local size-m transforms
-        PANDA_TRY(tw.ensure(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+        PANDA_TRY(tw.ensure(passes_table_bytes(log_m) + SZ_TA + SZ_TB + 4096));
     } else
         tw.used = 0;
     tw.valid = false;
@@ -1028,7 +1110,7 @@ hipError_t slab_inverse_local(const panda_ntt_slab_configuration &cfg, bool wait
         fe_from_wire(omega_inv, (const u32 *)cfg.omega);
         inverse_parameters<Fr>(omega_inv, scale, (u64)1 << cfg.log_n); // w^-1 and n^-1
         fe_pow_u64(omega_m, omega_inv, (u64)1 << cfg.log_ranks);
-        PANDA_TRY(tw.ensure(5 * (SZ_TA + SZ_TB + SZ_PQ) + 4096));
+        PANDA_TRY(tw.ensure(passes_table_bytes(log_m) + SZ_TA + SZ_TB + 4096));
     } else
         tw.used = 0;
     tw.valid = false;
@@ -1161,6 +1243,16 @@ panda_error panda_ntt_last_device_ms(float *ms)
 {
     if (!ms) return panda_error_invalid_value;
     *ms = g_pass_timer.ms;
+    return panda_success;
+}
+
+panda_error panda_ntt_pass_plan(unsigned log_n, unsigned *passes, unsigned *radix_bits)
+{
+    if (log_n > 28 || !passes) return panda_error_invalid_value;
+    const PassPlan pl = plan_passes(log_n, false);
+    *passes = pl.count;
+    if (radix_bits)
+        for (unsigned j = 0; j < 4; j++) radix_bits[j] = j < pl.count ? pl.d[j] : 0;
     return panda_success;
 }
 

@@ -407,6 +407,21 @@ def test_msm_phase_timers(gm):
 
 # ------------------------------------------------------------------ NTT
 
+def ntt_passes(log_n):
+    """passes of a natural-order transform (the library's plan: eight bits per pass as fft.cu:171-216, or radix-512 passes in front)"""
+    passes, bits = C.c_uint(0), (C.c_uint * 4)()
+    ffi.check(ffi.load().panda_ntt_pass_plan(log_n, C.byref(passes), bits), "plan")
+    assert sum(bits) == log_n and all(b <= 9 for b in bits)
+    return passes.value
+
+
+def test_ntt_pass_plan():
+    want = {17: 2, 18: 2, 25: 3, 26: 3, 27: 3}
+    for log_n in range(0, 29):
+        assert ntt_passes(log_n) == want.get(log_n, (log_n + 7) // 8), log_n
+    assert ffi.load().panda_ntt_pass_plan(29, C.byref(C.c_uint(0)), None) != 0
+
+
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_ntt_v1_vs_oracle(gm, log_n):
     fid = po.F_BN254_FR
@@ -416,7 +431,7 @@ def test_ntt_v1_vs_oracle(gm, log_n):
     want = po.ntt(fid, x, om, log_n)
     buf = x.copy()
     flag = pgm.panda_ntt_bn254_gpu_v1(gm, buf, om, log_n)
-    assert flag == ((log_n + 7) // 8) % 2  # same parity as the reference's pass loop (fft.cu:193-211)
+    assert flag == ntt_passes(log_n) % 2  # *flag = passes & 1 (fft.cu:211); the reference's loop runs ceil(log_n / 8) passes, 2^17 / 2^18 here one less
     assert (buf == want).all()
     # inverse with fused n^-1 returns the input
     back = buf.copy()
@@ -1695,11 +1710,12 @@ def test_process_exit_with_live_registration_and_scratch():
     assert r.returncode == 0 and "bye" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("log_n", [25, 26])
+@pytest.mark.parametrize("log_n", [25, 26, 27])
 def test_ntt_beyond_three_passes(gm, log_n):
-    """2^25 and 2^26 elements: a fourth pass of degree 1 / 2 whose inter-pass twiddle has a 25 / 26-bit exponent (the two-table path with
-    k split at 16 - deg bits).  Forward values by direct O(n) evaluation of three outputs, the whole inverse(forward(x)) buffer byte for
-    byte, and the bit-reversed orderings against the natural ones at sampled positions."""
+    """2^25 .. 2^27 elements.  Natural order: three passes with radix-512 passes in front (9 + 8 + 8, 9 + 9 + 8, 9 + 9 + 9; k_ntt_pass9, inter-pass
+    tables of up to 2^18 entries); the bit-reversed orderings: the eight-bit plan with a fourth pass of degree 1 / 2 / 3 whose inter-pass twiddle
+    has a 25 .. 27-bit exponent.  Forward values by direct O(n) evaluation of three outputs, the whole inverse(forward(x)) buffer byte for
+    byte, and the bit-reversed orderings (the other plan) against the natural ones at sampled positions."""
     fid = po.F_BN254_FR
     n = 1 << log_n
     lib = ffi.load()
@@ -1711,7 +1727,7 @@ def test_ntt_beyond_three_passes(gm, log_n):
     flag = C.c_uint(9)
     cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
     ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
-    assert flag.value == 0  # four passes (fft.cu:193-211)
+    assert ntt_passes(log_n) == 3 and flag.value == 1  # three passes: the result is in d_dst (fft.cu:211)
     fwd, other = (d_b, d_a) if flag.value else (d_a, d_b)
     ks = [1, n - 1, int(rng.integers(0, n))]
     vals = {k: fwd.to_host(nbytes=32, offset=k * 32) for k in ks}

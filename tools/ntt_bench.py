@@ -26,15 +26,22 @@ def main():
         ffi.check(lib.panda_gen_scalars(0, 3, 0, n, da.ptr, NULL_STREAM), "gen")
         flag = C.c_uint(0)
         cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, da.ptr, dbb.ptr, C.c_void_p(om.ctypes.data), k, C.pointer(flag))
-        ts = []
-        for r in range(reps + 1):
-            t = time.time()
-            ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
-            if r:
-                ts.append(time.time() - t)
-        ts.sort()
-        best, med = ts[0], ts[len(ts) // 2]
-        print(f"NTT bn254 2^{k}: best {best*1e3:8.3f} ms median {med*1e3:8.3f} ms  {n/med/1e9:8.3f} Gelem/s  {n*64/med/1e9:8.1f} GB/s algorithmic", flush=True)
+        ms = C.c_float(0)
+        for name, fn in (("natural", lib.panda_ntt_execute_bn254_v1), ("bitrev_out (eight-bit plan)", lib.panda_ntt_execute_bn254_bitrev_out)):
+            ts, ds = [], []
+            for r in range(reps + 1):
+                t = time.time()
+                ffi.check(fn(cfg), "ntt")
+                w = time.time() - t
+                ffi.check(lib.panda_ntt_last_device_ms(C.byref(ms)), "ms")
+                if r:
+                    ts.append(w)
+                    ds.append(ms.value)
+            ts.sort()
+            ds.sort()
+            best, med, dmed = ts[0], ts[len(ts) // 2], ds[len(ds) // 2]
+            print(f"NTT bn254 2^{k} {name}: wall best {best*1e3:8.3f} ms median {med*1e3:8.3f} ms | device median {dmed:8.3f} ms (best {ds[0]:.3f})  "
+                  f"{n/dmed/1e6:8.3f} Gelem/s  {n*64/dmed/1e6:8.1f} GB/s algorithmic", flush=True)
         da.free()
         dbb.free()
     gm.deinit()
