@@ -767,6 +767,7 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
             a.lgp = log_p;
             a.br_in = (br_in && passes == 0) ? 1 : 0;
             a.br_out = (br_out && last) ? 1 : 0;
+            a.tiles = (unsigned)(n / panda_ntt8::ELEMS);
             const unsigned deg2 = last ? 0 : pl.d[passes + 1]; // radix of the next pass (deg == full unless last)
             if (!last) {
                 // twiddle W^(i2 k2), W = w^(n / 2^(log_p + deg + deg2)), k2 < 2^(log_p + deg), i2 < 2^deg2; tables of at most 2^cap entries

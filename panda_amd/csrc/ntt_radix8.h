@@ -47,6 +47,7 @@ struct Pass8Args {
                        // tb[(i2 << cb) | (k2 >> ca)]
     unsigned br_in;    // first pass: the caller's input is in bit-reversed order
     unsigned br_out;   // last pass: leave the output in bit-reversed order
+    unsigned tiles;    // tiles of the pass (a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...)
     unsigned skip;     // LAST pass only: a pass of radix 2^(8 - skip), skip = 1 .. 4.  The top `skip` bits of the 8-bit local index then
                        // select the sub-transform instead of a position in it (a tile holds 8 << skip sub-transforms) and rounds
                        // 0 .. skip - 1 do not run; the twiddle indices of the remaining rounds are what they were (powers of the
@@ -210,6 +211,15 @@ __device__ __forceinline__ void exchange(Fe<Fr> (&e)[8], u32 *s_x, const unsigne
 
 // FIRST: input bound 2 (the caller's elements; nothing was multiplied onto them), else 3 (outputs of the previous pass's twiddle
 // product).  LAST: no output twiddle, canonical output.
+// experiment switch (tools/ntt8_variants.hip): the middle block's twiddles from the LDS copy of the table instead of scalar loads
+#ifdef P8_B_LDS
+#define P8_LOAD_B(t, idx) load_tw2(t, s_tw, idx)
+#define P8_B_UNIFORM false
+#else
+#define P8_LOAD_B(t, idx) load_tw2_uniform(t, A.pq, idx)
+#define P8_B_UNIFORM true
+#endif
+
 template <class Fr, bool FIRST, bool LAST, int PB, int MINW>
 __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
 {
@@ -221,7 +231,6 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
     const unsigned lane = tid & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned skip = LAST ? A.skip : 0u, deg = 8 - skip;
-    const unsigned blk0 = blockIdx.x * (SUBS << skip);
     const unsigned S = (1u << A.log_n) >> deg; // stride between the inputs of one sub-transform
     const unsigned lgp = A.lgp;
 
@@ -232,6 +241,14 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
 #pragma unroll
         for (int j = 0; j < 5; j++) l[j] = g[j];
     }
+#ifdef P8_PERSIST // experiment switch: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (costs registers: measured slower)
+#pragma unroll 1
+  for (unsigned tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
+#else
+  {
+    const unsigned tile = blockIdx.x;
+#endif
+    const unsigned blk0 = tile * (SUBS << skip);
 
     // ---- block A: thread (s, i0) holds i = i0 + 32 m of sub-transform s; rounds 0..2 (distances 128, 64, 32)
     Fe<Fr> e[8];
@@ -265,7 +282,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
             }
         }
     }
-    __syncthreads(); // s_tw complete
+    __syncthreads(); // s_tw complete (first tile); the previous tile's last exchange batch has been read by everyone (later ones)
 
     {
         TwV<Fr> t;
@@ -318,19 +335,19 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
         if (skip < 4) {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                load_tw2_uniform(t, A.pq, 8 * (4 * m + j0));
-                bfly<Fr, PL.b[3], true, PL.red[3], true, 1>(e[m], e[m + 4], t.w, t.q, m == 0 && w0);
+                P8_LOAD_B(t, 8 * (4 * m + j0));
+                bfly<Fr, PL.b[3], true, PL.red[3], P8_B_UNIFORM, 1>(e[m], e[m + 4], t.w, t.q, m == 0 && w0);
             }
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            load_tw2_uniform(t, A.pq, 16 * (4 * h + j0));
-            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h], e[h + 2], t.w, t.q, h == 0 && w0);
-            bfly<Fr, PL.b[4], true, PL.red[4], true, 0>(e[h + 4], e[h + 6], t.w, t.q, h == 0 && w0);
+            P8_LOAD_B(t, 16 * (4 * h + j0));
+            bfly<Fr, PL.b[4], true, PL.red[4], P8_B_UNIFORM, 0>(e[h], e[h + 2], t.w, t.q, h == 0 && w0);
+            bfly<Fr, PL.b[4], true, PL.red[4], P8_B_UNIFORM, 0>(e[h + 4], e[h + 6], t.w, t.q, h == 0 && w0);
         }
-        load_tw2_uniform(t, A.pq, 32 * j0);
+        P8_LOAD_B(t, 32 * j0);
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], true, 1>(e[m], e[m + 1], t.w, t.q, w0);
+        for (int m = 0; m < 8; m += 2) bfly<Fr, PL.b[5], true, PL.red[5], P8_B_UNIFORM, 1>(e[m], e[m + 1], t.w, t.q, w0);
     }
 
     // ---- exchange 2: element (s, i) lives at word b | (s << 5) | (i[2:0] << 8), b[1:0] = i[6:5] ^ i[4:3], b[4:2] = s ^ (i[7], i[4:3])
@@ -427,6 +444,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
             }
         }
     }
+  } // tiles
 }
 
 // ---- a short LAST pass (radix 2, 4 or 8) entirely in registers ------------------------------------------------------------------------

@@ -48,18 +48,23 @@ int main(int argc, char **argv)
     hipEvent_t e[4];
     for (auto &ev : e) hipEventCreate(&ev);
     const unsigned tiles = (unsigned)(n / ELEMS);
+#ifdef P8_PERSIST
+    const unsigned grid = V_PERSIST < tiles ? V_PERSIST : tiles; // workgroups that walk the tiles
+#else
+    const unsigned grid = tiles;
+#endif
     Pass8Args p1{}, p2{}, p3{};
-    p1.x = a; p1.y = b; p1.pq = pq; p1.ta = ta; p1.tb = tb; p1.log_n = log_n; p1.lgp = 0; p1.ca = 8; p1.cb = 0; p1.i2_shift = log_n - 16;
+    p1.x = a; p1.y = b; p1.pq = pq; p1.ta = ta; p1.tb = tb; p1.log_n = log_n; p1.lgp = 0; p1.ca = 8; p1.cb = 0; p1.i2_shift = log_n - 16; p1.tiles = tiles;
     p2 = p1; p2.x = b; p2.y = a; p2.lgp = 8; p2.ca = 8; p2.cb = 8; p2.i2_shift = log_n - 24;
     p3 = p1; p3.lgp = 16; p3.ca = p3.cb = 0;
     float best[4] = {1e9f, 1e9f, 1e9f, 1e9f}, sum[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps + 2; r++) {
         hipEventRecord(e[0]);
-        hipLaunchKernelGGL((k_ntt_pass8<F, true, false, V_PB, V_MINW>), dim3(tiles), dim3(THREADS), 0, 0, p1);
+        hipLaunchKernelGGL((k_ntt_pass8<F, true, false, V_PB, V_MINW>), dim3(grid), dim3(THREADS), 0, 0, p1);
         hipEventRecord(e[1]);
-        hipLaunchKernelGGL((k_ntt_pass8<F, false, false, V_PB, V_MINW>), dim3(tiles), dim3(THREADS), 0, 0, p2);
+        hipLaunchKernelGGL((k_ntt_pass8<F, false, false, V_PB, V_MINW>), dim3(grid), dim3(THREADS), 0, 0, p2);
         hipEventRecord(e[2]);
-        hipLaunchKernelGGL((k_ntt_pass8<F, false, true, V_PB, V_MINW>), dim3(tiles), dim3(THREADS), 0, 0, p3);
+        hipLaunchKernelGGL((k_ntt_pass8<F, false, true, V_PB, V_MINW>), dim3(grid), dim3(THREADS), 0, 0, p3);
         hipEventRecord(e[3]);
         hipEventSynchronize(e[3]);
         if (r < 2) continue;
