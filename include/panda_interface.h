@@ -298,6 +298,11 @@ panda_error panda_msm_execute_bls12_377_from_host_multi(panda_multi_gpu mg, cons
                                                         void *result);
 panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* n_dev */);
 panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
+/* A batch of `count` sharded transforms (same size and root; cfgs[t * n_dev + d] = rank d of transform t, every transform with its own slab and
+ * scratch) pipelined over two streams per device: the all-to-all of transform t runs while step 1 of transform t + 1 and step 2 of transform
+ * t - 1 compute.  Layouts, flags and results as `count` separate panda_ntt_execute_bn254[_inverse]_multi calls; one synchronisation at the end. */
+panda_error panda_ntt_execute_bn254_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* count x n_dev */, unsigned count);
+panda_error panda_ntt_execute_bn254_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count);
 /* per-phase device times of rank's last MSM inside a *_multi call (the workers' panda_msm_last_phase_ms) */
 panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms /* PANDA_MSM_PHASES floats */);
 

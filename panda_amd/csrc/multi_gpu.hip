@@ -87,6 +87,8 @@ struct MultiGpu {
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;                 // used when a configuration carries no stream of its own
     std::vector<hipStream_t> copy_streams;            // per device: the upload stream of the *_from_host_multi calls
+    std::vector<hipStream_t> xchg_streams;            // per device: the exchange stream of the batched transforms (ntt_multi_batch)
+    std::vector<std::vector<hipEvent_t>> events;      // per device: event pool of the batched transforms (grown on demand, kept)
     std::vector<void *> d_gather;                     // per device: n x MAX_RESULT_BYTES, partials of every rank
     std::vector<std::unique_ptr<Worker>> workers;
     std::vector<float> phase_ms;                      // n x PANDA_MSM_PHASES, from the workers' last MSM
@@ -120,6 +122,9 @@ struct MultiGpu {
             (void)hipSetDevice(devices[d]);
             if (d < streams.size() && streams[d]) (void)hipStreamDestroy(streams[d]);
             if (d < copy_streams.size() && copy_streams[d]) (void)hipStreamDestroy(copy_streams[d]);
+            if (d < xchg_streams.size() && xchg_streams[d]) (void)hipStreamDestroy(xchg_streams[d]);
+            if (d < events.size())
+                for (hipEvent_t ev : events[d]) (void)hipEventDestroy(ev);
             if (d < d_gather.size() && d_gather[d]) (void)hipFree(d_gather[d]);
         }
     }
@@ -280,6 +285,126 @@ hipError_t ntt_multi(MultiGpu &mg, const panda_ntt_slab_configuration *cfgs, sla
     return e;
 }
 
+// A batch of sharded transforms with the exchange of transform t hidden behind the kernels of its neighbours ("a sharded
+// transform that overlaps its exchange").  Inside ONE transform the all-to-all cannot start before the last pass of step 1 has finished (every tile
+// of that pass writes into every rank's chunk); a prover, however, transforms many polynomials with the same root, so the
+// batch is pipelined instead: every device has a compute stream (the caller's, or the handle's) and an exchange stream,
+//     compute  : step1(0) step1(1) step2(0) step1(2) step2(1) ...          exchange : x(0) x(1) x(2) ...
+// with x(t) waiting for step1(t) by event and step2(t) waiting for x(t).  Transform t's slab and scratch are its own (cfgs[t * n + d]); layouts, flags
+// and results are those of `count` separate panda_ntt_execute_*_multi calls.  One host synchronisation at the end.
+hipError_t ntt_multi_batch(MultiGpu &mg, const panda_ntt_slab_configuration *cfgs, unsigned count, slab_fn first, slab_fn second)
+{
+    if (!cfgs || count == 0 || count > 4096) return hipErrorInvalidValue;
+    unsigned log_ranks = 0;
+    while ((1u << log_ranks) < mg.n) log_ranks++;
+    if ((1u << log_ranks) != mg.n) return hipErrorInvalidValue;
+    const unsigned n = mg.n;
+    for (unsigned t = 0; t < count; t++)
+        for (unsigned d = 0; d < n; d++) {
+            const panda_ntt_slab_configuration &c = cfgs[(size_t)t * n + d];
+            if (c.rank != d || c.log_ranks != log_ranks || c.log_n != cfgs[0].log_n || c.log_n < 2 * log_ranks || !c.d_slab || !c.d_scratch || !c.omega) return hipErrorInvalidValue;
+        }
+    std::lock_guard<std::mutex> call(mg.call_mutex);
+    int caller_dev = 0;
+    PANDA_TRY(hipGetDevice(&caller_dev));
+    const size_t slab_bytes = (size_t)32 << (cfgs[0].log_n - log_ranks), chunk = slab_bytes >> log_ranks;
+    std::vector<hipStream_t> streams(n);
+    for (unsigned d = 0; d < n; d++) streams[d] = stream_of(mg, d, cfgs[d].stream);
+    // two events per transform and device: step 1 enqueued-and-done (E1), exchange done (E2)
+    hipError_t e = hipSuccess;
+    for (unsigned d = 0; e == hipSuccess && d < n; d++) {
+        e = hipSetDevice(mg.devices[d]);
+        while (e == hipSuccess && mg.events[d].size() < 2 * (size_t)count) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) mg.events[d].push_back(ev);
+        }
+    }
+    auto E1 = [&](unsigned t, unsigned d) { return mg.events[d][2 * t]; };
+    auto E2 = [&](unsigned t, unsigned d) { return mg.events[d][2 * t + 1]; };
+    std::vector<unsigned> flag1((size_t)count * n, 0), flag2((size_t)count * n, 0);
+    std::vector<char *> src((size_t)count * n), dst((size_t)count * n);
+    for (unsigned t = 0; e == hipSuccess && t <= count; t++) {
+        // compute streams: step 1 of transform t, then step 2 of transform t - 1 (whose exchange is under way or done)
+        e = mg.on_all([&, t](unsigned d) -> hipError_t {
+            if (t < count) {
+                panda_ntt_slab_configuration c = cfgs[(size_t)t * n + d];
+                c.stream.handle = streams[d];
+                c.flag = &flag1[(size_t)t * n + d];
+                const panda_error pe = first(c); // enqueued; the flag is valid on return
+                if (pe != panda_success) return static_cast<hipError_t>(pe);
+                PANDA_TRY(hipEventRecord(E1(t, d), streams[d]));
+            }
+            if (t > 0) {
+                const unsigned u = t - 1;
+                // RCCL: my receives are complete when my exchange stream reaches E2.  Loopback: the peers copy OUT of my step-1 buffer on their
+                // exchange streams, and step 2 uses that buffer as its scratch: wait for all of them.
+                if (mg.transport == PANDA_MULTI_RCCL)
+                    PANDA_TRY(hipStreamWaitEvent(streams[d], E2(u, d), 0));
+                else
+                    for (unsigned q = 0; q < n; q++) PANDA_TRY(hipStreamWaitEvent(streams[d], E2(u, q), 0));
+                panda_ntt_slab_configuration c = cfgs[(size_t)u * n + d];
+                c.stream.handle = streams[d];
+                c.d_slab = dst[(size_t)u * n + d];
+                c.d_scratch = src[(size_t)u * n + d];
+                c.flag = &flag2[(size_t)u * n + d];
+                const panda_error pe = second(c);
+                if (pe != panda_success) return static_cast<hipError_t>(pe);
+            }
+            return hipSuccess;
+        });
+        if (e != hipSuccess || t == count) break;
+        // exchange streams: transform t's all-to-all behind its step 1
+        for (unsigned d = 0; d < n; d++) {
+            const panda_ntt_slab_configuration &c = cfgs[(size_t)t * n + d];
+            const bool f = flag1[(size_t)t * n + d] != 0;
+            src[(size_t)t * n + d] = (char *)(f ? c.d_scratch : c.d_slab);
+            dst[(size_t)t * n + d] = (char *)(f ? c.d_slab : c.d_scratch);
+        }
+        char **sr = &src[(size_t)t * n], **ds = &dst[(size_t)t * n];
+        if (mg.transport == PANDA_MULTI_RCCL) {
+            for (unsigned d = 0; e == hipSuccess && d < n; d++) {
+                e = hipSetDevice(mg.devices[d]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(mg.xchg_streams[d], E1(t, d), 0);
+            }
+            if (e == hipSuccess)
+                e = nccl_group([&]() -> hipError_t {
+                    for (unsigned d = 0; d < n; d++)
+                        for (unsigned q = 0; q < n; q++) {
+                            PANDA_TRY_NCCL(ncclSend(sr[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], mg.xchg_streams[d]));
+                            PANDA_TRY_NCCL(ncclRecv(ds[d] + q * chunk, chunk, ncclChar, (int)q, mg.comms[d], mg.xchg_streams[d]));
+                        }
+                    return hipSuccess;
+                });
+        } else {
+            for (unsigned d = 0; e == hipSuccess && d < n; d++) {
+                e = hipSetDevice(mg.devices[d]);
+                for (unsigned q = 0; e == hipSuccess && q < n; q++) e = hipStreamWaitEvent(mg.xchg_streams[d], E1(t, q), 0); // every rank's step 1
+                for (unsigned q = 0; e == hipSuccess && q < n; q++)
+                    e = hipMemcpyAsync(ds[d] + q * chunk, sr[q] + d * chunk, chunk, hipMemcpyDefault, mg.xchg_streams[d]);
+            }
+        }
+        for (unsigned d = 0; e == hipSuccess && d < n; d++) {
+            e = hipSetDevice(mg.devices[d]);
+            if (e == hipSuccess) e = hipEventRecord(E2(t, d), mg.xchg_streams[d]);
+        }
+    }
+    // one wait at the end; on errors too nothing of this call stays in flight
+    const hipError_t drained_x = sync_all(mg, mg.xchg_streams), drained_c = sync_all(mg, streams);
+    if (e == hipSuccess) e = drained_x;
+    if (e == hipSuccess) e = drained_c;
+    if (e == hipSuccess)
+        for (unsigned t = 0; t < count; t++)
+            for (unsigned d = 0; d < n; d++) {
+                const panda_ntt_slab_configuration &c = cfgs[(size_t)t * n + d];
+                const size_t i = (size_t)t * n + d;
+                const char *out = flag2[i] ? src[i] : dst[i];
+                if (c.flag) *(unsigned *)c.flag = out == (const char *)c.d_scratch ? 1u : 0u;
+            }
+    (void)hipSetDevice(caller_dev);
+    return e;
+}
+
 MultiGpu *handle_of(panda_multi_gpu mg) { return static_cast<MultiGpu *>(mg.handle); }
 
 } // namespace
@@ -303,6 +428,8 @@ panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, uns
     mg->devices.assign(devices, devices + n_dev);
     mg->streams.assign(n_dev, nullptr);
     mg->copy_streams.assign(n_dev, nullptr);
+    mg->xchg_streams.assign(n_dev, nullptr);
+    mg->events.assign(n_dev, std::vector<hipEvent_t>());
     mg->d_gather.assign(n_dev, nullptr);
     mg->phase_ms.assign((size_t)n_dev * PANDA_MSM_PHASES, 0.f);
     hipError_t e = hipSuccess;
@@ -310,6 +437,7 @@ panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, uns
         e = hipSetDevice(devices[d]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->streams[d], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->copy_streams[d], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mg->xchg_streams[d], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(&mg->d_gather[d], (size_t)n_dev * MAX_RESULT_BYTES);
     }
     if (e == hipSuccess && transport == PANDA_MULTI_RCCL) {
@@ -401,6 +529,19 @@ panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const pand
     if (!mg.handle) return panda_error_invalid_value;
     return static_cast<panda_error>(
         ntt_multi(*handle_of(mg), cfgs, panda_ntt_slab_inverse_step1_bn254_enqueue, panda_ntt_slab_inverse_step2_bn254_enqueue));
+}
+
+panda_error panda_ntt_execute_bn254_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(ntt_multi_batch(*handle_of(mg), cfgs, count, panda_ntt_slab_step1_bn254_enqueue, panda_ntt_slab_step2_bn254_enqueue));
+}
+
+panda_error panda_ntt_execute_bn254_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        ntt_multi_batch(*handle_of(mg), cfgs, count, panda_ntt_slab_inverse_step1_bn254_enqueue, panda_ntt_slab_inverse_step2_bn254_enqueue));
 }
 
 panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms)

@@ -299,6 +299,21 @@ class MultiGpu:
         ffi.check(fn(self.handle, cfgs), "SchedulingErr")
         return [f.value for f in flags]
 
+    def ntt_batch(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None):
+        """panda_ntt_execute_bn254[_inverse]_multi_batch: slabs[t][d] / scratches[t][d] are the device pointers of rank d of transform t; the exchange
+        of transform t overlaps the kernels of its neighbours.  Returns flags[t][d] (1: the output is in scratches[t][d])."""
+        count = len(slabs)
+        assert count >= 1 and len(scratches) == count and all(len(a) == self.n and len(b) == self.n for a, b in zip(slabs, scratches))
+        g = _log2_exact(self.n)
+        om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
+        flags = [[C.c_uint(7) for _ in range(self.n)] for _ in range(count)]
+        cfgs = (ffi.NttSlabConfiguration * (self.n * count))(*[
+            ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[t][d]), C.c_void_p(scratches[t][d]), C.c_void_p(om.ctypes.data),
+                                     log_n, g, d, C.pointer(flags[t][d])) for t in range(count) for d in range(self.n)])
+        fn = self.lib.panda_ntt_execute_bn254_inverse_multi_batch if inverse else self.lib.panda_ntt_execute_bn254_multi_batch
+        ffi.check(fn(self.handle, cfgs, count), "SchedulingErr")
+        return [[f.value for f in row] for row in flags]
+
     def phases(self, rank: int):
         ph = (C.c_float * 8)()
         ffi.check(self.lib.panda_multi_gpu_last_phase_ms(self.handle, rank, ph), "SchedulingErr")

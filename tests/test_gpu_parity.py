@@ -727,6 +727,49 @@ def test_c_abi_multi_gpu_ntt(gm, ranks, transport, log_n):
             d.free()
 
 
+@pytest.mark.parametrize("ranks,transport,log_n,count", [(1, ffi.MULTI_RCCL, 12, 3), (2, ffi.MULTI_LOOPBACK, 10, 4), (4, ffi.MULTI_LOOPBACK, 14, 3), (8, ffi.MULTI_LOOPBACK, 20, 5)])
+def test_c_abi_multi_gpu_ntt_batch(gm, ranks, transport, log_n, count):
+    """panda_ntt_execute_bn254_multi_batch / _inverse_multi_batch: `count` sharded transforms of different inputs pipelined over a compute and an
+    exchange stream per device (the all-to-all of transform t behind step 1 of t + 1 and step 2 of t - 1).  Every transform against the oracle's
+    plain transform, the inverse batch back to the decimated input slabs; run twice (the second round reuses the handle's events and the workers'
+    twiddle caches)."""
+    fid = po.F_BN254_FR
+    n = 1 << log_n
+    m = n // ranks
+    om = po.root_of_unity(fid, log_n)
+    xs = [po.gen_scalars(fid, 0xBA7C + 16 * t + log_n, n) for t in range(count)]
+    wants = [po.ntt(fid, x, om, log_n) for x in xs]
+    slabs = [[DeviceBuffer(m * 32) for _ in range(ranks)] for _ in range(count)]
+    scratches = [[DeviceBuffer(m * 32) for _ in range(ranks)] for _ in range(count)]
+    mg = multi_gpu.MultiGpu([0] * ranks, transport)
+    try:
+        for _ in range(2):
+            for t in range(count):
+                for r in range(ranks):
+                    part = multi_gpu.slab_of(xs[t], ranks, r)  # held while the copy runs
+                    ffi.check(ffi.load().panda_memcpy(slabs[t][r].ptr, C.c_void_p(part.ctypes.data), m * 32), "copy")
+            flags = mg.ntt_batch([[b.ptr.value for b in row] for row in slabs], [[b.ptr.value for b in row] for row in scratches], om, log_n)
+            for t in range(count):
+                outs = [(scratches[t][r] if flags[t][r] else slabs[t][r]).to_host().reshape(m, 8) for r in range(ranks)]
+                assert (multi_gpu.natural_from_slab_outputs(outs) == wants[t]).all(), t
+            src = [[(scratches[t][r], slabs[t][r]) if flags[t][r] else (slabs[t][r], scratches[t][r]) for r in range(ranks)] for t in range(count)]
+            back = mg.ntt_batch([[a.ptr.value for a, _ in row] for row in src], [[b.ptr.value for _, b in row] for row in src], om, log_n, inverse=True)
+            for t in range(count):
+                for r in range(ranks):
+                    got = (src[t][r][1] if back[t][r] else src[t][r][0]).to_host().reshape(m, 8)
+                    assert (got == multi_gpu.slab_of(xs[t], ranks, r)).all(), (t, r)
+        lib = ffi.load()
+        assert lib.panda_ntt_execute_bn254_multi_batch(mg.handle, None, 1) == 1  # panda_error_invalid_value
+        one = (ffi.NttSlabConfiguration * ranks)(*[ffi.NttSlabConfiguration(ffi.PandaStream(), slabs[0][r].ptr, scratches[0][r].ptr, C.c_void_p(om.ctypes.data), log_n,
+                                                                              ranks.bit_length() - 1, r, None) for r in range(ranks)])
+        assert lib.panda_ntt_execute_bn254_multi_batch(mg.handle, one, 0) == 1
+    finally:
+        mg.close()
+        for row in slabs + scratches:
+            for d in row:
+                d.free()
+
+
 def test_c_abi_multi_gpu_handles_from_two_threads(gm):
     """Two panda_multi_gpu handles alive at once (two sets of worker threads), each driven from its own host thread while the other is
     busy, created and destroyed three times over: every call returns the MSM of its own inputs."""
