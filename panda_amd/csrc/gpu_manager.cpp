@@ -480,10 +480,17 @@ PandaGpuError PandaMultiGpuManager::msm_bn254_with_cached_bases(Bytes scalars, s
 
 PandaGpuError PandaMultiGpuManager::ntt_bn254(uint8_t *data, size_t len, Bytes omega, uint32_t log_n)
 {
-    const size_t G = managers.size(), n = (size_t)1 << log_n;
+    return ntt_bn254_batch(std::vector<uint8_t *>{data}, len, omega, log_n);
+}
+
+PandaGpuError PandaMultiGpuManager::ntt_bn254_batch(const std::vector<uint8_t *> &polys, size_t len, Bytes omega, uint32_t log_n)
+{
+    const size_t G = managers.size(), n = (size_t)1 << log_n, count = polys.size();
     uint32_t log_g = 0;
     while (((size_t)1 << log_g) < G) log_g++;
-    if (((size_t)1 << log_g) != G || len < n * FIELD_ELEMENT_LEN || omega.len < FIELD_ELEMENT_LEN || log_n < 2 * log_g) return PandaGpuError::NttExecErr;
+    if (((size_t)1 << log_g) != G || count == 0 || len < n * FIELD_ELEMENT_LEN || omega.len < FIELD_ELEMENT_LEN || log_n < 2 * log_g) return PandaGpuError::NttExecErr;
+    for (uint8_t *p : polys)
+        if (!p) return PandaGpuError::NttExecErr;
     const size_t m = n / G, chunk = m / G;
     struct Staged {
         std::vector<void *> ptrs;
@@ -494,29 +501,33 @@ PandaGpuError PandaMultiGpuManager::ntt_bn254(uint8_t *data, size_t len, Bytes o
                 if (ptrs[i] && panda_set_device(dev[i]) == 0) (void)panda_free(ptrs[i]);
         }
     } staged;
-    std::vector<panda_ntt_slab_configuration> cfgs(G);
-    std::vector<unsigned> flags(G, 0);
+    std::vector<panda_ntt_slab_configuration> cfgs(G * count);
+    std::vector<unsigned> flags(G * count, 0);
     std::vector<uint8_t> slab(m * FIELD_ELEMENT_LEN);
-    for (size_t d = 0; d < G; d++) { // rank d holds the decimated sequence x[d + G j]
-        for (size_t j = 0; j < m; j++) std::memcpy(slab.data() + j * FIELD_ELEMENT_LEN, data + (d + G * j) * FIELD_ELEMENT_LEN, FIELD_ELEMENT_LEN);
-        if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
-        void *a = nullptr, *b = nullptr;
-        if (panda_malloc(&a, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
-        staged.ptrs.push_back(a);
-        staged.dev.push_back(devices_[d]);
-        if (panda_malloc(&b, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
-        staged.ptrs.push_back(b);
-        staged.dev.push_back(devices_[d]);
-        if (panda_memcpy(a, slab.data(), m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
-        cfgs[d] = panda_ntt_slab_configuration{managers[d].get_exec_stream(), a, b, const_cast<uint8_t *>(omega.data), log_n, log_g, (unsigned)d, &flags[d]};
-    }
-    if (panda_ntt_execute_bn254_multi(handle, cfgs.data()) != 0) return PandaGpuError::NttExecErr;
-    for (size_t q = 0; q < G; q++) { // rank q holds y[k1 m + q m/G + k2'] at [k1][k2']
-        if (set_device((size_t)devices_[q]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
-        if (panda_memcpy(slab.data(), flags[q] ? cfgs[q].d_scratch : cfgs[q].d_slab, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
-        for (size_t k1 = 0; k1 < G; k1++)
-            std::memcpy(data + (k1 * m + q * chunk) * FIELD_ELEMENT_LEN, slab.data() + k1 * chunk * FIELD_ELEMENT_LEN, chunk * FIELD_ELEMENT_LEN);
-    }
+    for (size_t t = 0; t < count; t++)
+        for (size_t d = 0; d < G; d++) { // rank d holds the decimated sequence x[d + G j]
+            for (size_t j = 0; j < m; j++) std::memcpy(slab.data() + j * FIELD_ELEMENT_LEN, polys[t] + (d + G * j) * FIELD_ELEMENT_LEN, FIELD_ELEMENT_LEN);
+            if (set_device((size_t)devices_[d]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+            void *a = nullptr, *b = nullptr;
+            if (panda_malloc(&a, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+            staged.ptrs.push_back(a);
+            staged.dev.push_back(devices_[d]);
+            if (panda_malloc(&b, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncPoolMallocErr;
+            staged.ptrs.push_back(b);
+            staged.dev.push_back(devices_[d]);
+            if (panda_memcpy(a, slab.data(), m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
+            cfgs[t * G + d] = panda_ntt_slab_configuration{managers[d].get_exec_stream(), a, b, const_cast<uint8_t *>(omega.data), log_n, log_g, (unsigned)d, &flags[t * G + d]};
+        }
+    const panda_error pe = count == 1 ? panda_ntt_execute_bn254_multi(handle, cfgs.data()) : panda_ntt_execute_bn254_multi_batch(handle, cfgs.data(), (unsigned)count);
+    if (pe != 0) return PandaGpuError::NttExecErr;
+    for (size_t t = 0; t < count; t++)
+        for (size_t q = 0; q < G; q++) { // rank q holds y[k1 m + q m/G + k2'] at [k1][k2']
+            const panda_ntt_slab_configuration &c = cfgs[t * G + q];
+            if (set_device((size_t)devices_[q]) != PandaGpuError::Ok) return PandaGpuError::SetDeviceError;
+            if (panda_memcpy(slab.data(), flags[t * G + q] ? c.d_scratch : c.d_slab, m * FIELD_ELEMENT_LEN) != 0) return PandaGpuError::AsyncMemcopyErr;
+            for (size_t k1 = 0; k1 < G; k1++)
+                std::memcpy(polys[t] + (k1 * m + q * chunk) * FIELD_ELEMENT_LEN, slab.data() + k1 * chunk * FIELD_ELEMENT_LEN, chunk * FIELD_ELEMENT_LEN);
+        }
     return set_device((size_t)devices_[0]);
 }
 

@@ -153,6 +153,9 @@ class PandaMultiGpuManager {
     // forward transform of 2^log_n elements given in natural order; `data` receives y in natural order (the slabs are decimated
     // on the way in and the output layout y[k1 m + q m/G + k2'] at rank q's [k1][k2'] is undone on the way out)
     PandaGpuError ntt_bn254(uint8_t *data, size_t len, Bytes omega, uint32_t log_n);
+    // the same for several polynomials of one size behind ONE call (panda_ntt_execute_bn254_multi_batch: the exchange of polynomial t runs
+    // beside the kernels of its neighbours); every polys[t] is transformed in place
+    PandaGpuError ntt_bn254_batch(const std::vector<uint8_t *> &polys, size_t len, Bytes omega, uint32_t log_n);
 
     std::vector<PandaGpuManager> managers;
     panda_multi_gpu handle{};

@@ -346,10 +346,18 @@ int main(int argc, char **argv)
         root_of_unity(omega, log_n);
         y = x;
         REQUIRE(panda_ntt_bn254_gpu_v1(gm, y.data(), y.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+        std::vector<uint8_t> x2 = x, x3 = y; // a batch of three polynomials (the third is the first one's transform)
+        for (size_t i = 0; i < x2.size(); i += 32) x2[i] ^= 1; // still below p: bit 0 of the lowest limb
+        std::vector<uint8_t> y2 = x2, y3 = x3;
+        REQUIRE(panda_ntt_bn254_gpu_v1(gm, y2.data(), y2.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+        REQUIRE(panda_ntt_bn254_gpu_v1(gm, y3.data(), y3.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
         REQUIRE(mgm.ntt_bn254(x.data(), x.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
         REQUIRE(x == y);
+        std::vector<uint8_t> b1 = x2, b2 = x3, b3 = x2;
+        REQUIRE(mgm.ntt_bn254_batch({b1.data(), b2.data(), b3.data()}, b1.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+        REQUIRE(b1 == y2 && b2 == y3 && b3 == y2);
         REQUIRE(mgm.deinit() == PandaGpuError::Ok);
-        printf("PandaMultiGpuManager: sharded MSM 2^15 (registered and tabled) and NTT 2^13 from host slices ok\n");
+        printf("PandaMultiGpuManager: sharded MSM 2^15 (registered and tabled), NTT 2^13 and a pipelined batch of three from host slices ok\n");
     }
     REQUIRE(gm.deinit() == PandaGpuError::Ok);
     printf("manager_test: all ok\n");
