@@ -287,6 +287,8 @@ panda_error panda_multi_gpu_destroy(panda_multi_gpu mg);
 panda_error panda_multi_gpu_device_count(panda_multi_gpu mg, unsigned *n_dev);
 panda_error panda_msm_execute_bn254_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs /* n_dev */, void *result /* host */);
 panda_error panda_msm_execute_bls12_377_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result);
+panda_error panda_msm_execute_bls12_381_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result /* 144 B */);
+panda_error panda_msm_execute_bn254_g2_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result /* 192 B */);
 /* The same with the scalars starting on the HOST ("scalars H2D'd per shard"; replaces the staging of unit.rs:103-188, which
  * uploads before it executes): h_scalars[d] is rank d's host source (pinned memory lets the copies run beside the kernels, pageable
  * memory works), cfgs[d].scalars the device buffer it lands in.  Every device's worker runs panda_msm_execute_from_host on its shard --
@@ -296,6 +298,10 @@ panda_error panda_msm_execute_bn254_from_host_multi(panda_multi_gpu mg, const pa
                                                     unsigned ranges, void *result /* host */);
 panda_error panda_msm_execute_bls12_377_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges,
                                                         void *result);
+panda_error panda_msm_execute_bls12_381_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges,
+                                                        void *result);
+panda_error panda_msm_execute_bn254_g2_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges,
+                                                       void *result);
 panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* n_dev */);
 panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
 /* A batch of `count` sharded transforms (same size and root; cfgs[t * n_dev + d] = rank d of transform t, every transform with its own slab and

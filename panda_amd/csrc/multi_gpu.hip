@@ -487,6 +487,20 @@ panda_error panda_msm_execute_bls12_377_multi(panda_multi_gpu mg, const panda_ms
         msm_multi(*handle_of(mg), cfgs, result, 144, [](unsigned, const panda_msm_configuration &c) { return panda_msm_execute_bls12_377(c); }, panda_msm_combine_bls12_377));
 }
 
+panda_error panda_msm_execute_bls12_381_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        msm_multi(*handle_of(mg), cfgs, result, 144, [](unsigned, const panda_msm_configuration &c) { return panda_msm_execute_bls12_381(c); }, panda_msm_combine_bls12_381));
+}
+
+panda_error panda_msm_execute_bn254_g2_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, void *result)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        msm_multi(*handle_of(mg), cfgs, result, 192, [](unsigned, const panda_msm_configuration &c) { return panda_msm_execute_bn254_g2(c); }, panda_msm_combine_bn254_g2));
+}
+
 // Scalars that start on the HOST (north_star / SURVEY 8e: "scalars H2D'd per shard"; unit.rs:103-188 stages them before it executes):
 // every worker runs the in-call upload pipeline of panda_msm_execute_from_host on its own shard -- its own arena, helper stream, copy
 // stream and PCIe link -- so the G uploads run side by side and each hides behind its shard's kernels.
@@ -516,6 +530,17 @@ panda_error panda_msm_execute_bls12_377_from_host_multi(panda_multi_gpu mg, cons
                                                         void *result)
 {
     return msm_from_host_multi(mg, 1, 144, panda_msm_combine_bls12_377, cfgs, h_scalars, ranges, result);
+}
+
+panda_error panda_msm_execute_bls12_381_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges,
+                                                        void *result)
+{
+    return msm_from_host_multi(mg, 2, 144, panda_msm_combine_bls12_381, cfgs, h_scalars, ranges, result);
+}
+
+panda_error panda_msm_execute_bn254_g2_from_host_multi(panda_multi_gpu mg, const panda_msm_configuration *cfgs, const void *const *h_scalars, unsigned ranges, void *result)
+{
+    return msm_from_host_multi(mg, 3, 192, panda_msm_combine_bn254_g2, cfgs, h_scalars, ranges, result);
 }
 
 panda_error panda_ntt_execute_bn254_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)

@@ -84,6 +84,7 @@ ADDITIVE_SYMBOLS = [
     "panda_debug_field_op", "panda_debug_curve_op", "panda_version",
     "panda_multi_gpu_create", "panda_multi_gpu_destroy", "panda_multi_gpu_device_count", "panda_msm_execute_bn254_multi", "panda_msm_execute_bls12_377_multi",
     "panda_msm_execute_bn254_from_host_multi", "panda_msm_execute_bls12_377_from_host_multi",
+    "panda_msm_execute_bls12_381_multi", "panda_msm_execute_bn254_g2_multi", "panda_msm_execute_bls12_381_from_host_multi", "panda_msm_execute_bn254_g2_from_host_multi",
     "panda_ntt_execute_bn254_multi", "panda_ntt_execute_bn254_inverse_multi", "panda_ntt_execute_bn254_multi_batch", "panda_ntt_execute_bn254_inverse_multi_batch", "panda_multi_gpu_last_phase_ms",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
@@ -144,6 +145,9 @@ def load() -> C.CDLL:
         "panda_msm_execute_bn254_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp], "panda_msm_execute_bls12_377_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp],
         "panda_msm_execute_bn254_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
         "panda_msm_execute_bls12_377_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
+        "panda_msm_execute_bls12_381_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp], "panda_msm_execute_bn254_g2_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp],
+        "panda_msm_execute_bls12_381_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
+        "panda_msm_execute_bn254_g2_from_host_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), C.POINTER(vp), u, vp],
         "panda_ntt_execute_bn254_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)], "panda_ntt_execute_bn254_inverse_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)],
         "panda_ntt_execute_bn254_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint], "panda_ntt_execute_bn254_inverse_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
         "panda_multi_gpu_last_phase_ms": [PandaMultiGpu, u, C.POINTER(C.c_float)],

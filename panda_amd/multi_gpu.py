@@ -267,21 +267,23 @@ class MultiGpu:
 
     def msm(self, cfgs, curve: int = 0) -> np.ndarray:
         """panda_msm_execute_*_multi: base ranges on the devices, one all-gather of partials, the total on the host."""
-        assert len(cfgs) == self.n and curve in (0, 1)
+        assert len(cfgs) == self.n and curve in (0, 1, 2, 3)  # BN254, BLS12-377, BLS12-381 (G1), BN254 G2
         arr = (ffi.MSMConfiguration * self.n)(*cfgs)
-        out = np.zeros(96 if curve == 0 else 144, dtype=np.uint8)
-        fn = self.lib.panda_msm_execute_bn254_multi if curve == 0 else self.lib.panda_msm_execute_bls12_377_multi
+        out = np.zeros((96, 144, 144, 192)[curve], dtype=np.uint8)
+        fn = (self.lib.panda_msm_execute_bn254_multi, self.lib.panda_msm_execute_bls12_377_multi, self.lib.panda_msm_execute_bls12_381_multi,
+              self.lib.panda_msm_execute_bn254_g2_multi)[curve]
         ffi.check(fn(self.handle, arr, C.c_void_p(out.ctypes.data)), "SchedulingErr")
         return out
 
     def msm_from_host(self, cfgs, host_ptrs, ranges: int = 4, curve: int = 0) -> np.ndarray:
         """panda_msm_execute_*_from_host_multi: as msm(), with rank d's scalars starting at host address host_ptrs[d] (pinned or
         pageable) and crossing PCIe inside the call -- every device uploads its own shard, in `ranges` point ranges, beside its kernels."""
-        assert len(cfgs) == len(host_ptrs) == self.n and curve in (0, 1)
+        assert len(cfgs) == len(host_ptrs) == self.n and curve in (0, 1, 2, 3)
         arr = (ffi.MSMConfiguration * self.n)(*cfgs)
         hp = (C.c_void_p * self.n)(*[C.c_void_p(int(p)) for p in host_ptrs])
-        out = np.zeros(96 if curve == 0 else 144, dtype=np.uint8)
-        fn = self.lib.panda_msm_execute_bn254_from_host_multi if curve == 0 else self.lib.panda_msm_execute_bls12_377_from_host_multi
+        out = np.zeros((96, 144, 144, 192)[curve], dtype=np.uint8)
+        fn = (self.lib.panda_msm_execute_bn254_from_host_multi, self.lib.panda_msm_execute_bls12_377_from_host_multi,
+              self.lib.panda_msm_execute_bls12_381_from_host_multi, self.lib.panda_msm_execute_bn254_g2_from_host_multi)[curve]
         ffi.check(fn(self.handle, arr, hp, ranges, C.c_void_p(out.ctypes.data)), "SchedulingErr")
         return out
 
