@@ -535,6 +535,8 @@ def main():
         # building, tens of GB of traffic) the chip's sustained clock is ~10 % lower and they would be timed on a heat-soaked GPU
         leg("config2_msm_2_20", lambda: small_config(ctx, 0, 20, ctx.ffi.JACOBIAN, 20, "BN254 MSM 2^20, Jacobian output, cached bases (BASELINE config 2)"))
         leg("msm_2_22", lambda: small_config(ctx, 0, 22, ctx.ffi.JACOBIAN, 10, "BN254 MSM 2^22, Jacobian output, cached bases (north_star sweep 2^20 ... 2^26)"))
+    if world == 1 and not args.no_ntt:
+        leg("ntt", lambda: ntt_figure(ctx, sweep=not args.no_ntt_sweep))  # BASELINE config 3, also millisecond-sized: before the heavy legs, for the same reason
     if world == 1 and not args.no_compare:
         leg("pcie_inclusive", lambda: pcie_inclusive(ctx, prob))
         if prob.tables > 1:
@@ -548,11 +550,8 @@ def main():
 
     if not args.no_config4 and world & (world - 1) == 0 and world <= 64:
         leg("config4_msm_2_26", lambda: config4(ctx, args.config4_total_log_n))
-    if not args.no_ntt:
-        if world == 1:
-            leg("ntt", lambda: ntt_figure(ctx, sweep=not args.no_ntt_sweep))
-        elif world & (world - 1) == 0:
-            leg("ntt_sharded", lambda: ntt_sharded_figure(ctx))
+    if not args.no_ntt and world > 1 and world & (world - 1) == 0:
+        leg("ntt_sharded", lambda: ntt_sharded_figure(ctx))
     if world == 1 and not args.no_extra_configs:
         leg("config5_bls12_377_2_24_projective",
             lambda: small_config(ctx, 1, 24, ctx.ffi.PROJECTIVE, 5, "BLS12-377 MSM 2^24 + Projective-output conversion (BASELINE config 5)"))
