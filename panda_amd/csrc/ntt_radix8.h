@@ -192,6 +192,9 @@ template <class Fr, int PB, int RSTEP>
 __device__ __forceinline__ void exchange(Fe<Fr> (&e)[8], u32 *s_x, const unsigned (&wa)[8], unsigned ra)
 {
     Fe<Fr> n[8];
+#ifdef P8_PRIO // experiment switch: exchange phases at raised wave priority (a workgroup parked at a barrier holds four waves' registers)
+    __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
     for (int p0 = 0; p0 < NL; p0 += PB) {
         if (p0 != 0) __syncthreads(); // the previous batch has been read by everyone
@@ -207,6 +210,9 @@ __device__ __forceinline__ void exchange(Fe<Fr> (&e)[8], u32 *s_x, const unsigne
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) e[m] = n[m];
+#ifdef P8_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // FIRST: input bound 2 (the caller's elements; nothing was multiplied onto them), else 3 (outputs of the previous pass's twiddle
