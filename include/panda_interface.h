@@ -214,7 +214,8 @@ panda_error panda_ntt_execute_bn254_inverse(const panda_ntt_configuration_v1 exe
 panda_error panda_ntt_last_device_ms(float *ms);
 /* The passes a natural-order transform of 2^log_n points runs: their number (the reference's loop, fft.cu:171-216, takes eight bits per
  * pass; here 2^17/2^18 and 2^25..2^27 run one pass less behind radix-512 passes) and, if radix_bits != NULL, the bits of each (four
- * entries, zero-padded).  *flag of the execute calls is passes & 1; the bit-reversed orderings keep the eight-bit plan. */
+ * entries, zero-padded).  *flag of the execute calls is passes & 1.  The bit-reversed orderings run the same number of passes (radix-512
+ * passes last for a bit-reversed input) except at 2^18 and 2^27, where they keep the eight-bit plan. */
 panda_error panda_ntt_pass_plan(unsigned log_n, unsigned *passes, unsigned *radix_bits);
 /* Bit-reversed orderings (SURVEY 8f-4 "bit-reversed NTT variants"): the forward transform with y[k] stored at bitrev(k), and the inverse
  * (n^-1 fused) of a buffer in that order back to natural-order coefficients.  Chaining them skips two permutations. */

@@ -411,36 +411,41 @@ const size_t SZ_PQ9 = panda::align256((size_t)256 * panda_ntt8::TW2_STRIDE * 4);
 
 // The radices of a transform's passes.  The reference's loop (fft.cu:171-216) takes eight bits per pass and whatever is left in the
 // last one; sizes whose bit count leaves a short last pass behind three (two) full ones run one pass less with radix-512 passes in
-// front: 2^17 = 9 + 8, 2^18 = 9 + 9, 2^25 = 9 + 8 + 8, 2^26 = 9 + 9 + 8, 2^27 = 9 + 9 + 9.  The bit-reversed orderings keep the
-// eight-bit plan (their address maps live in k_ntt_pass8).  *flag = passes & 1 either way: callers read it (unit.rs:458-470).
+// front: 2^17 = 9 + 8, 2^18 = 9 + 9, 2^25 = 9 + 8 + 8, 2^26 = 9 + 9 + 8, 2^27 = 9 + 9 + 9 (bit-reversed orderings: see plan_passes).
+// *flag = passes & 1 either way: callers read it (unit.rs:458-470).
 struct PassPlan {
     unsigned count = 0;
     unsigned d[8] = {0};
     bool wide = false; // contains a radix-512 pass
 };
 
-PassPlan plan_passes(unsigned log_n, bool bit_reversed)
+PassPlan plan_passes(unsigned log_n, bool br_in = false, bool br_out = false)
 {
     PassPlan pl;
+    // radix-512 passes in front; the address maps of the bit-reversed orderings live in the radix-256 kernel, so a bit-reversed INPUT wants
+    // that kernel first (the radix-512 passes then go last: 8 + 9, 8 + 8 + 9, 8 + 9 + 9) and a bit-reversed OUTPUT wants it last, which
+    // the plans with a radix-256 tail already give; 2^18 / 2^27 (all passes radix 512) and both orderings at once keep the eight-bit plan
     unsigned nines = 0;
-    if (!bit_reversed) {
-        switch (log_n) {
-        case 17: case 25: nines = 1; break;
-        case 18: case 26: nines = 2; break;
-        case 27: nines = 3; break;
-        default: break;
-        }
+    switch (log_n) {
+    case 17: case 25: nines = 1; break;
+    case 18: case 26: nines = 2; break;
+    case 27: nines = 3; break;
+    default: break;
     }
-    unsigned left = log_n;
-    for (unsigned j = 0; j < nines; j++) {
-        pl.d[pl.count++] = 9;
-        left -= 9;
-    }
+    if ((br_in && br_out) || ((br_in || br_out) && nines * 9 == log_n)) nines = 0;
     pl.wide = nines != 0;
+    unsigned eights[8], ne = 0, left = log_n - 9 * nines;
     while (left) {
         const unsigned deg = left < 8 ? left : 8;
-        pl.d[pl.count++] = deg;
+        eights[ne++] = deg;
         left -= deg;
+    }
+    if (br_in) { // radix-256 passes first (with nines != 0 they are all full: 17, 25, 26 leave multiples of eight)
+        for (unsigned j = 0; j < ne; j++) pl.d[pl.count++] = eights[j];
+        for (unsigned j = 0; j < nines; j++) pl.d[pl.count++] = 9;
+    } else {
+        for (unsigned j = 0; j < nines; j++) pl.d[pl.count++] = 9;
+        for (unsigned j = 0; j < ne; j++) pl.d[pl.count++] = eights[j];
     }
     return pl;
 }
@@ -455,9 +460,9 @@ PassTables pass_tables(const PassPlan &pl, unsigned j)
     return PassTables{last ? 256 : SZ_T18, last ? 256 : SZ_T18, SZ_PQ9};
 }
 // bytes ntt_passes carves out of its arena for a transform of 2^log_n points
-size_t passes_table_bytes(unsigned log_n, bool bit_reversed = false)
+size_t passes_table_bytes(unsigned log_n, bool br_in = false, bool br_out = false)
 {
-    const PassPlan pl = plan_passes(log_n, bit_reversed);
+    const PassPlan pl = plan_passes(log_n, br_in, br_out);
     size_t total = 0;
     for (unsigned j = 0; j < pl.count; j++) {
         const PassTables t = pass_tables(pl, j);
@@ -740,7 +745,7 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
-    const PassPlan pl = plan_passes(log_n, br_in || br_out);
+    const PassPlan pl = plan_passes(log_n, br_in, br_out);
     const unsigned total_passes = pl.count;
     // Transforms of 2^11 points and more run their radix-256 / radix-512 passes in k_ntt_pass8 / k_ntt_pass9, which multiply the twiddle
     // between two passes onto the OUTPUT of the earlier one; a shorter last pass (k_ntt_small) then finds it done.  Smaller transforms
@@ -873,7 +878,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     PANDA_TRY(order_after_null_stream(stream));
     TwiddleCache &tw = g_twiddles[TW_WHOLE];
     u32 key[12];
-    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | ((br_in || br_out) ? 2u : 0u), omega_wire); // the bit-reversed orderings may run another plan
+    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u), omega_wire); // the bit-reversed orderings may run another plan
     PANDA_TRY(tw.settle(stream));
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
@@ -884,7 +889,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
         fe_from_wire(omega, omega_wire);
         if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in || br_out) + 4096));
+        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in, br_out) + 4096));
     } else
         tw.used = 0;
     tw.valid = false;
@@ -1250,7 +1255,7 @@ panda_error panda_ntt_last_device_ms(float *ms)
 panda_error panda_ntt_pass_plan(unsigned log_n, unsigned *passes, unsigned *radix_bits)
 {
     if (log_n > 28 || !passes) return panda_error_invalid_value;
-    const PassPlan pl = plan_passes(log_n, false);
+    const PassPlan pl = plan_passes(log_n);
     *passes = pl.count;
     if (radix_bits)
         for (unsigned j = 0; j < 4; j++) radix_bits[j] = j < pl.count ? pl.d[j] : 0;

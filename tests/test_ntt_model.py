@@ -14,7 +14,7 @@ def test_pass_formulas_compose_to_the_transform():
 
 def test_pass9_thread_maps_and_bank_conflicts():
     # (log_n, lgp, d2, last, tiles): a first pass (one table), a last pass, a middle pass shape, a first pass in front of a radix-256 pass
-    for log_n, lgp, d2, last, tiles in ((18, 0, 9, False, (0, 127)), (18, 9, 0, True, (77,)), (20, 9, 2, False, (300,)), (19, 0, 8, False, (200,))):
+    for log_n, lgp, d2, last, tiles in ((18, 0, 9, False, (0, 127)), (18, 9, 0, True, (77,)), (20, 9, 2, False, (300,)), (19, 0, 8, False, (200,)), (17, 8, 0, True, (63,)), (20, 8, 3, False, (511,))):  # the last two: behind a radix-256 pass (bit-reversed input plans)
         assert mp.check_pass9(log_n, lgp, d2, last, tiles) == 1  # every LDS access of both exchanges is conflict-free
 
 

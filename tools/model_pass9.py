@@ -297,6 +297,6 @@ if __name__ == "__main__":
         check_plan(log_n, radices)
     print("pass formulas: ok")
     for log_n, lgp, d2, last, tiles in ((18, 0, 9, False, (0, 5, 127)), (18, 9, 0, True, (0, 77)), (20, 9, 2, False, (3, 300)),
-                                        (19, 0, 8, False, (1, 200)), (12, 0, 3, False, (0, 1))):
+                                        (19, 0, 8, False, (1, 200)), (12, 0, 3, False, (0, 1)), (17, 8, 0, True, (0, 63)), (20, 8, 3, False, (5, 511))):
         worst = check_pass9(log_n, lgp, d2, last, tiles)
         print(f"pass9 threads log_n={log_n} lgp={lgp} d2={d2} last={last}: ok, worst LDS bank multiplicity {worst}")

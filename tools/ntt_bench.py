@@ -27,7 +27,7 @@ def main():
         flag = C.c_uint(0)
         cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, da.ptr, dbb.ptr, C.c_void_p(om.ctypes.data), k, C.pointer(flag))
         ms = C.c_float(0)
-        for name, fn in (("natural", lib.panda_ntt_execute_bn254_v1), ("bitrev_out (eight-bit plan)", lib.panda_ntt_execute_bn254_bitrev_out)):
+        for name, fn in (("natural", lib.panda_ntt_execute_bn254_v1), ("bitrev_out", lib.panda_ntt_execute_bn254_bitrev_out)):
             ts, ds = [], []
             for r in range(reps + 1):
                 t = time.time()
