@@ -44,6 +44,9 @@ POINT_BYTES = {0: 64, 1: 96, 2: 96, 3: 128}
 RESULT_BYTES = {0: 96, 1: 144, 2: 144, 3: 192}
 # v_mad_u64_u32 lane-operations per second, whole chip, 8 waves per SIMD: profiles/r01_ubench_int_rates.txt ("mad_u64_u32 ... 28450.16 Gop/s")
 MAD_PEAK_PER_S = 28.45e12
+# ... and what one bare dependent chain in a single asm block sustains at four waves per SIMD (tools/ubench_nop.hip): the instruction's own rate,
+# which no multiplication reaches -- every product column also needs a mask and a 64-bit shift on the same vector pipe
+MAD_BARE_CHAIN_PER_S = 33.4e12
 # multiply-adds of one XYZZ mixed addition on 9 x 29-bit limbs: 8 products of 162, 2 squarings of 126, one shared reduction
 # (counted in the ISA of k_accumulate<Bn254Fq>)
 MADS_PER_ADDITION_BN254 = 1467
@@ -513,6 +516,9 @@ def main():
             out["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "kernel": "k_accumulate", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
                                      "unit": "T mad lane-ops/s", "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions,
                                      "mads_per_addition": MADS_PER_ADDITION_BN254, "kernel_ms": acc_kernel_ms,
+                                     "frac_of_bare_chain_rate": mads / MAD_BARE_CHAIN_PER_S,
+                                     "valu_model": "4.7 cycles per multiply-add + 4 per other vector instruction on one vector pipe per SIMD reproduces the kernel's time "
+                                                   "within 6 % (DESIGN.md section 7): the pipe is saturated, ~30 % of it by the masks, shifts and additions around the products",
                                      "peak_source": "profiles/r01_ubench_int_rates.txt: mad_u64_u32 at 8 waves/SIMD, 28450 Gop/s (a sub-millisecond launch at the nominal "
                                                     "2.4 GHz; this kernel sustains ~2.0 GHz at ~1240 W, profiles/r02_accumulate_stalls.txt)"}
 
