@@ -154,7 +154,9 @@ template <class F, int K>
 __device__ inline __attribute__((always_inline)) void fe29_mul_col(uint64_t &acc, const uint32_t *a, const uint32_t *b, uint32_t *m, uint32_t *out)
 {
     constexpr int N = F::N;
-    if constexpr (K < N)
+    if constexpr (K == 0)
+        MacChain<1>::vv0(acc, a, b); // column 0 starts the accumulator (no register pair to clear)
+    else if constexpr (K < N)
         MacChain<K + 1>::vv(acc, a, b + K);
     else
         MacChain<2 * N - 1 - K>::vv(acc, a + (K - N + 1), b + (N - 1));
@@ -167,7 +169,10 @@ __device__ inline __attribute__((always_inline)) void fe29_sqr_col(uint64_t &acc
     constexpr int I0 = K < N ? 0 : K - N + 1;
     constexpr int CNT = (K + 1) / 2 - I0; // cross terms a2[i] * a[K - i], I0 <= i, 2 i < K
     MacChain<CNT>::vv(acc, a2 + I0, a + (K - I0));
-    if constexpr ((K & 1) == 0) MacChain<1>::vv(acc, a + K / 2, a + K / 2);
+    if constexpr (K == 0)
+        MacChain<1>::vv0(acc, a, a);
+    else if constexpr ((K & 1) == 0)
+        MacChain<1>::vv(acc, a + K / 2, a + K / 2);
     fe29_reduce_col<F, K>(acc, m, out);
 }
 template <class F, int... K>
@@ -180,7 +185,10 @@ __device__ inline __attribute__((always_inline)) void fe29_mul_add_col(uint64_t 
                                                                        uint32_t *out)
 {
     constexpr int N = F::N;
-    if constexpr (K < N) {
+    if constexpr (K == 0) {
+        MacChain<1>::vv0(acc, a, b);
+        MacChain<1>::vv(acc, c, d);
+    } else if constexpr (K < N) {
         MacChain<K + 1>::vv(acc, a, b + K);
         MacChain<K + 1>::vv(acc, c, d + K);
     } else {
@@ -667,7 +675,12 @@ __device__ inline __attribute__((always_inline)) void fe29_shoup_hi_col(uint64_t
     constexpr int N = F::N;
     constexpr int I0 = C < N ? 0 : C - N + 1;
     constexpr int CNT = (C < N ? C : N - 1) - I0 + 1;
-    if constexpr (UNIFORM)
+    if constexpr (C == N - 2) { // the first column of the quotient product starts the accumulator
+        if constexpr (UNIFORM)
+            MacChain<CNT>::vs0(acc, x + I0, wq + (C - I0));
+        else
+            MacChain<CNT>::vv0(acc, x + I0, wq + (C - I0));
+    } else if constexpr (UNIFORM)
         MacChain<CNT>::vs(acc, x + I0, wq + (C - I0));
     else
         MacChain<CNT>::vv(acc, x + I0, wq + (C - I0));
@@ -682,7 +695,12 @@ __device__ inline __attribute__((always_inline)) void fe29_shoup_hi_cols(uint64_
 template <class F, bool UNIFORM, int C>
 __device__ inline __attribute__((always_inline)) void fe29_shoup_lo_col(uint64_t &acc, const uint32_t *x, const uint32_t *w, const uint32_t *q, uint32_t *out)
 {
-    if constexpr (UNIFORM)
+    if constexpr (C == 0) { // column 0 of the low halves starts the accumulator afresh
+        if constexpr (UNIFORM)
+            MacChain<1>::vs0(acc, x, w);
+        else
+            MacChain<1>::vv0(acc, x, w);
+    } else if constexpr (UNIFORM)
         MacChain<C + 1>::vs(acc, x, w + C);
     else
         MacChain<C + 1>::vv(acc, x, w + C);
