@@ -89,6 +89,9 @@ def parse():
                          "a worker thread and an RCCL communicator per device inside the library) instead of one torch.distributed rank per GPU")
     ap.add_argument("--loopback", action="store_true", help="--single-process rehearsal on a one-GPU box: every rank on device 0, device copies instead of RCCL")
     ap.add_argument("--no-c-abi-leg", action="store_true", help="N > 1: do not run the single-process C-ABI leg after the torch.distributed legs")
+    ap.add_argument("--launcher-note", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--detail", default=None, help="also write the un-shortened record (every leg's full dictionary) to this file; "
+                                                   "default: gpurun_out/bench_detail_n<N>.json when gpurun_out/ exists")
     return ap.parse_args()
 
 
@@ -207,10 +210,9 @@ class MsmProblem:
         self.tables, self.wbits, self.held = tb.value, wb.value, held.value
         self.registered = True
         if self.tables > 1:
-            self.mode = (f"cached: resident, registered with {self.tables} precomputed window tables of {self.wbits}-bit windows "
-                         f"(panda_msm_precompute_bases: {self.held / 2**30:.1f} GiB, built once in {self.t_reg:.2f} s, outside the timed region)")
+            self.mode = f"cached: {self.tables} window tables of {self.wbits} bits ({self.held / 2**30:.1f} GiB, built in {self.t_reg:.2f} s before the timed region)"
         else:
-            self.mode = "cached: resident and registered (panda_msm_register_bases)"
+            self.mode = "cached: registered (panda_msm_register_bases), no tables"
 
     def execute(self):
         self.ctx.ffi.check(self.fn(self.cfg), "SchedulingErr")
@@ -320,9 +322,9 @@ def single_process(args) -> dict:
                 t1 = time.perf_counter()
                 mg.msm_from_host(cfgs, [h.value for h in hosts], 5)
                 best = min(best, time.perf_counter() - t1)
-            from_host.update({"value": G * per / best, "unit": "points/s", "ms": best * 1e3, "ranges": 5,
-                              "note": "panda_msm_execute_bn254_from_host_multi: every rank's scalars cross PCIe from pinned host memory inside the call, "
-                                      "in point ranges beside its kernels; all ranks upload side by side"})
+            # panda_msm_execute_bn254_from_host_multi: every rank's scalars cross PCIe from pinned host memory inside the call, in point
+            # ranges beside its kernels; all ranks upload side by side
+            from_host.update({"value": G * per / best, "unit": "points/s", "from_host_multi_ms": best * 1e3, "ranges": 5})
             for h in hosts:
                 lib.panda_free_host(h)
         for dev, b, sc, r in bufs:
@@ -428,15 +430,181 @@ def c_abi_leg(args, world: int) -> dict:
     return json.loads(lines[-1])
 
 
+def _sig(x, digits: int = 5):
+    """numbers of the contract line carry five significant digits: the line has to fit the 8 KB the driver keeps of it"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def contract_line(full: dict) -> dict:
+    """The ONE line the driver records, cut down from the run's full record (`--detail` keeps that): the contract's keys, then
+    `configs_ms` -- milliseconds per call of every BASELINE.json configuration and sweep size, flat --, `roofline`, `cpu_baseline`, and the
+    few numbers behind each.  No prose: what the keys mean is in DESIGN.md section 7."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _sig(full[k]) for k in keys if k in full}
+    line["config"] = {k: v for k, v in full.get("config", {}).items() if not isinstance(v, dict)}
+    if full.get("launcher"):
+        line["launcher"] = full["launcher"]
+
+    ms = {}
+
+    def put(name, *path, scale=1.0):
+        v = _get(full, *path)
+        if isinstance(v, (int, float)) and v > 0:
+            ms[name] = _sig(v * scale, 4)
+
+    put("c2_msm_2_20_tables", "config2_msm_2_20", "with_tables", "ms_per_step")
+    put("c2_msm_2_20_registered", "config2_msm_2_20", "registered_only", "ms_per_step")
+    put("c3_ntt_2_24_fwd", "ntt", "ms")
+    put("c3_ntt_2_24_inv", "ntt", "inverse_ms")
+    put("c4_msm_2_26_total", "config4_msm_2_26", "ms_per_step")
+    put("c5_bls377_2_24_proj_tables", "config5_bls12_377_2_24_projective", "with_tables", "ms_per_step")
+    put("c5_bls377_2_24_proj_registered", "config5_bls12_377_2_24_projective", "registered_only", "ms_per_step")
+    put("msm_2_24_registered", "without_tables", "ms_per_step")
+    put("msm_2_24_unregistered", "without_tables", "unregistered", "ms_per_step")
+    put("msm_2_24_from_host_one_call", "pcie_inclusive", "single_call_pipelined", "ms")
+    put("msm_2_24_upload_then_execute", "pcie_inclusive", "ms")
+    put("msm_2_22_tables", "msm_2_22", "with_tables", "ms_per_step")
+    put("msm_2_22_registered", "msm_2_22", "registered_only", "ms_per_step")
+    for k in (20, 22, 26):
+        put(f"ntt_2_{k}_fwd", "ntt", "sweep", f"2^{k}", "ms")
+    put("ntt_bls377_2_24_fwd", "ntt_bls12_377", "ms")
+    put("ntt_bls377_2_24_inv", "ntt_bls12_377", "inverse_ms")
+    put("g2_msm_2_20_tables", "bn254_g2_msm_2_20", "with_tables", "ms_per_step")
+    put("ntt_sharded_2_24_total", "ntt_sharded", "strong_2_24_total", "ms")
+    put("ntt_sharded_2_24_total_inv", "ntt_sharded", "strong_2_24_total", "inverse_ms")
+    put("ntt_sharded_2_24_per_gpu", "ntt_sharded", "weak_2_24_per_gpu", "ms")
+    put("ntt_sharded_batch4_per_transform", "ntt_sharded", "strong_2_24_total", "batch_of_4_ms_per_transform")
+    put("c_abi_msm_2_24_per_gpu", "c_abi_single_process", "ms_per_step")
+    put("c_abi_c4_msm_2_26_total", "c_abi_single_process", "configs_ms", "c4_msm_2_26_total")
+    put("c_abi_ntt_sharded_2_24_total", "c_abi_single_process", "configs_ms", "ntt_sharded_2_24_total")
+    put("c_abi_msm_2_24_from_host", "c_abi_single_process", "configs_ms", "msm_2_24_from_host_one_call")
+    put("msm_2_24_from_host_one_call", "pcie_inclusive", "from_host_multi_ms")  # --single-process: panda_msm_execute_bn254_from_host_multi
+    line["configs_ms"] = ms
+    c4 = full.get("config4_msm_2_26")
+    if isinstance(c4, dict) and "log_points_per_gpu" in c4:
+        line["c4_shape"] = {"n_gpus": c4.get("n_gpus"), "log_points_per_gpu": c4["log_points_per_gpu"], "scaling": "strong"}
+
+    rf = full.get("roofline")
+    if rf:
+        line["roofline"] = {k: _sig(v) for k, v in rf.items()}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: _sig(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
+        if "multi_thread" in cb:
+            line["cpu_baseline"]["value_16_threads"] = _sig(cb["multi_thread"]["value"])
+    ri = full.get("roofline_issue")
+    if ri:
+        line["roofline_issue"] = {k: _sig(ri[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "additions_per_launch", "mads_per_addition") if k in ri}
+    if "phases_ms" in full:
+        line["phases_ms"] = {k: _sig(v, 4) for k, v in full["phases_ms"].items()}
+    vr = {f"2^{k}": _sig(_get(full, leg, "vs_reference_model", "value"), 3) for k, leg in ((20, "config2_msm_2_20"), (22, "msm_2_22")) if _get(full, leg, "vs_reference_model", "value")}
+    if _get(full, "vs_reference_model", "value"):
+        vr["2^24"] = _sig(full["vs_reference_model"]["value"], 3)
+    if vr:
+        line["vs_reference_model"] = dict(vr, kind="model")
+    for name in ("ntt", "ntt_bls12_377"):
+        nt = full.get(name)
+        if isinstance(nt, dict) and "ms" in nt:
+            line[name] = {"value": _sig(nt["value"]), "unit": "elements/s", "ms": _sig(nt["ms"], 4), "passes": nt.get("passes"), "radix_bits": nt.get("radix_bits"),
+                          "roofline": {"bound": "hbm", "achieved": _sig(_get(nt, "roofline", "achieved")), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _sig(_get(nt, "roofline", "frac"), 4)},
+                          "issue_frac": _sig(_get(nt, "roofline_issue", "frac"), 4)}
+    kms = {}
+    for short, leg in (("c2", "config2_msm_2_20"), ("2_22", "msm_2_22"), ("c5", "config5_bls12_377_2_24_projective")):
+        v = _get(full, leg, "with_tables", "k_accumulate_ms")
+        if v:
+            kms[short] = _sig(v, 4)
+            f = _get(full, leg, "with_tables", "roofline_issue", "frac")
+            if f:
+                kms[short + "_issue_frac"] = _sig(f, 3)
+    if kms:
+        line["k_accumulate_ms"] = kms
+    for k in ("device_ms_per_step", "device_ms_by_rank"):
+        if k in full:
+            line[k] = _sig(full[k]) if isinstance(full[k], float) else full[k]
+    for leg, v in full.items():
+        if isinstance(v, dict) and "error" in v and leg not in line:
+            line[leg] = {"error": v["error"][:200]}
+    for k in ("failed_legs", "soft_failed_legs"):
+        if k in full:
+            line[k] = full[k]
+    return line
+
+
+def emit(full: dict, args) -> None:
+    """print the contract line; keep the un-shortened record beside it where the builder's profiling runs pick it up"""
+    if args.launcher_note:
+        full["launcher"] = args.launcher_note
+    path = args.detail
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        path = os.path.join(ROOT, "gpurun_out", f"bench_detail_n{full.get('n_gpus', 1)}.json")
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f)
+        except OSError:
+            pass
+    print(json.dumps(contract_line(full)), flush=True)
+
+
+def launch_ranks(args, argv=None, run=None) -> int:
+    """`python bench.py --gpus N` typed without a launcher in front: start torch.distributed.run on this file as a CHILD process --
+    before anything in this process has touched the GPU (a process that has never re-executes or replaces itself) --, pass its
+    output through and return its exit code.  If the launcher is missing, or its run ends without a contract line, the same N devices
+    are measured through the single-process C entry points instead (again in a child), and the line says so (`launcher`)."""
+    import importlib.util
+    import socket
+    import subprocess
+
+    argv = list(sys.argv[1:] if argv is None else argv)
+    me = os.path.abspath(__file__)
+
+    def child(cmd):
+        """run `cmd`, echo its stdout line by line, return (rc, whether a contract line went by)"""
+        if run is not None:
+            return run(cmd)
+        seen = False
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1)
+        for ln in p.stdout:
+            seen = seen or (ln.startswith("{") and '"metric"' in ln)
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        return p.wait(), seen
+
+    why = "torch.distributed.run is not importable"
+    if importlib.util.find_spec("torch") is not None and importlib.util.find_spec("torch.distributed.run") is not None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        rc, seen = child([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), me] + argv)
+        if seen:
+            return rc
+        why = f"torch.distributed.run ended with rc {rc} and no contract line"
+    print(f"bench.py: {why}; measuring the {args.gpus} devices through the single-process C entry points", file=sys.stderr, flush=True)
+    keep = [a for a in argv if a != "--no-c-abi-leg"]
+    rc, _ = child([sys.executable, me] + keep + ["--single-process", "--launcher-note", why])
+    return rc
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.single_process and world == 1:
-        print(json.dumps(single_process(args)), flush=True)
+        emit(single_process(args), args)
         return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1 (or pass --single-process)")
+            raise SystemExit(launch_ranks(args))
         args.gpus = world
     ctx = Ctx(args)
     lib, rank = ctx.lib, ctx.rank
@@ -547,11 +715,6 @@ def main():
         leg("pcie_inclusive", lambda: pcie_inclusive(ctx, prob))
         if prob.tables > 1:
             leg("without_tables", lambda: without_tables(ctx, prob, max(2, args.steps // 2)))
-            if rank == 0 and "ms_per_step" in out.get("without_tables", {}):
-                wt = out["without_tables"]
-                out["config"]["plain_call_without_tables"] = {"registered_ms_per_step": round(wt["ms_per_step"], 3),
-                                                              "unregistered_ms_per_step": round(wt.get("unregistered", {}).get("ms_per_step", 0.0), 3),
-                                                              "windows": wt.get("windows")}
     prob.release()
 
     if not args.no_config4 and world & (world - 1) == 0 and world <= 64:
@@ -581,7 +744,7 @@ def main():
             out["failed_legs"] = failed
         if soft_failed:  # legs the builder could not rehearse on real hardware (RCCL with more than one rank): reported, exit code kept
             out["soft_failed_legs"] = soft_failed
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if world > 1:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

@@ -199,6 +199,14 @@ panda_error panda_msm_set_window_bits(unsigned window_bits);
 panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned *window_bits, unsigned *windows);
 /* sorted entries per thread of the bucket-accumulation kernel, for experiments: 0 = built-in policy (rounded up to a multiple of 4) */
 panda_error panda_msm_set_chunk_entries(unsigned entries);
+/* With precomputed tables, levels 2 and 3 of the bucket sort for all but the first front_of_128 / 128 of the bucket space run on a second
+ * stream of the calling host thread, beside the accumulation of that front part (which is launched as workgroups_per_cu workgroups per
+ * CU so that the sort's workgroups find room next to it; 64 = the ordinary grid).  front_of_128: 1 .. 127, 0 = one stream, one phase
+ * after the other, 0xffffffff = built-in policy (default: off -- measured slower on MI355X for BN254, profiles/r05_overlap_sort_accumulate.txt);
+ * workgroups_per_cu: 0 = built-in (6 for BN254, three waves per SIMD), at most 64.  Same group element. */
+panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu);
+/* deprecated no-op kept so that code linked against the round-3 interface still loads (the bucket reduction has no groups any more) */
+panda_error panda_msm_set_reduce_group(unsigned log_group);
 /* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = none (default),
  * 1 = the call's total + the bucket-accumulation kernel, 2 = every phase.  Phases that were not timed read 0 in panda_msm_last_phase_ms. */
 panda_error panda_msm_set_phase_timing(unsigned level);

@@ -88,7 +88,9 @@ hipError_t thread_helper_stream(hipStream_t *out)
     if (e != hipSuccess) return e;
     if (g_helper.s && g_helper.device != dev) g_helper.drop();
     if (!g_helper.s) {
-        e = hipStreamCreateWithFlags(&g_helper.s, hipStreamNonBlocking); // ordered against the caller's stream by events only
+        // ordered against the caller's stream by events only.  PANDA_HELPER_PRIORITY (experiments): a priority for the stream
+        const char *prio = getenv("PANDA_HELPER_PRIORITY");
+        e = prio ? hipStreamCreateWithPriority(&g_helper.s, hipStreamNonBlocking, atoi(prio)) : hipStreamCreateWithFlags(&g_helper.s, hipStreamNonBlocking);
         if (e != hipSuccess) {
             g_helper.s = nullptr;
             return e;
@@ -206,6 +208,20 @@ std::atomic<unsigned> g_window_override{0};
 std::atomic<unsigned> g_chunk{0};
 std::atomic<unsigned> g_phase_timing{0};
 std::atomic<unsigned> g_paranoid{0};
+constexpr unsigned kOverlapAuto = 0xffffffffu;
+std::atomic<unsigned> g_overlap_front{kOverlapAuto};
+std::atomic<unsigned> g_overlap_wgs{0};
+
+// With tables, the accumulation of the first `front / 128` of the bucket space can run beside the sort of the rest (msm_impl.h,
+// "want_split").  Measured in round 5 and NOT the policy (profiles/r05_overlap_sort_accumulate.txt): k_accumulate<Bn254Fq> needs its
+// four waves per SIMD (three: -22 %), and those hold 94 % of the register file, so the second stream's sort workgroups are only
+// dispatched once the accumulate grid has nothing left to place (+0.6 ms at 2^24); a grid small enough to leave them room costs the
+// accumulate more than the 1.7 ms of sort it hides.  The option stays for experiments and for fields whose accumulate leaves room.
+unsigned pick_overlap_front(unsigned)
+{
+    const unsigned forced = g_overlap_front.load(std::memory_order_relaxed);
+    return forced != kOverlapAuto ? forced : 0u;
+}
 
 const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort_partition", "sort_buckets", "accumulate",
                                                    "fixup", "bucket_reduce", "d2h+host_horner", "total_device"};
@@ -259,7 +275,7 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale, const panda::MsmPipeline *pipe)
 {
     const panda::MsmTuning tuning{pick_window_bits(panda::msm_scalar_field_of(curve), cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
-                                  g_phase_timing.load(std::memory_order_relaxed)};
+                                  g_phase_timing.load(std::memory_order_relaxed), pick_overlap_front(cfg.log_scalars_count), g_overlap_wgs.load(std::memory_order_relaxed)};
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
     case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
@@ -510,6 +526,16 @@ panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned
     if (windows) *windows = plan.W;
     return panda_success;
 }
+
+panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu)
+{
+    if ((front_of_128 >= 128 && front_of_128 != kOverlapAuto) || workgroups_per_cu > 64) return panda_error_invalid_value;
+    g_overlap_front.store(front_of_128, std::memory_order_relaxed);
+    g_overlap_wgs.store(workgroups_per_cu, std::memory_order_relaxed);
+    return panda_success;
+}
+
+panda_error panda_msm_set_reduce_group(unsigned) { return panda_success; } // round-3 knob of a kernel that no longer exists
 
 panda_error panda_msm_set_chunk_entries(unsigned entries)
 {

@@ -56,6 +56,8 @@ struct MsmTuning {
     unsigned window_bits;  // plain-mode window width (already resolved by the policy)
     unsigned chunk;        // sorted entries per k_accumulate thread, 0 = built-in
     unsigned timing;       // 0: no device timers at all; 1: the call's total + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
+    unsigned overlap_front; // with tables: size of the front part of the bucket space, in 1/128, whose accumulation runs beside the sort of the rest (0 = no overlap)
+    unsigned overlap_wgs;   // workgroups per CU of that accumulation (6 = three waves per SIMD); 0 = the curve's default
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -330,29 +332,22 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 #ifndef ACC_RAW_Y
 #define ACC_RAW_Y false
 #endif
+// Which chunks of the list a launch owns.  pos == nullptr: all of them (one launch per list).  Otherwise the sort was split
+// (SortSplit, msm_sort.h): pos[] are the positions of the level-3 cells in the list, and the launch owns the chunks that END in
+// (pos[lo], pos[hi]] -- every entry and every bucket offset such a chunk reads is final once the cells below `hi` are merged, so the
+// front of the list is accumulated while the rest is still being sorted.  `last` marks the launch that also takes the list's final,
+// possibly short chunk; hi_bucket is the first bucket of cell `hi` (the offsets beyond it may not exist yet).
+struct AccPart {
+    const u32 *pos;
+    unsigned lo, hi, last, hi_bucket;
+};
+
 template <class F>
-__global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
-                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
-                                                    unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale)
+__device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, const u32 *__restrict__ sw, const u32 *__restrict__ ow, u32 *__restrict__ bw, u32 *__restrict__ pw,
+                                                 unsigned search_hi, u32 start, u32 end)
 {
     constexpr int PW = 4 * F::N;
-    const unsigned w = blockIdx.y;
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= chunks) return;
-    if (t == 0) long_count[w] = 0; // the fix-up's queue of long buckets starts empty (it runs behind this kernel on the same stream)
-    // the registered buffer no longer holds what was registered (the digits kernel of this range found out): the call will be repeated
-    // from the caller's buffer, and nine tenths of the work it would waste are in this kernel
-    if (stale && *stale) return;
-    const u32 *ow = off + (u64)w * (NB + 1);
-    const u32 nw = ow[NB];
-    const u32 start = t * K;
-    if (start >= nw) return;
-    const u32 end = min(start + K, nw);
-    const u32 *sw = sorted + (u64)w * stride;
-    u32 *pw = parts + ((u64)w * chunks + t) * 2 * PW;
-    u32 *bw = bucket_acc + (u64)w * NB * PW;
-
-    u32 b = owner_bucket(ow, NB, start);
+    u32 b = owner_bucket(ow, search_hi, start);
     u32 next = ow[b + 1];
     bool run_starts_inside = ow[b] >= start; // only the first run of a chunk can have begun in an earlier chunk
     Xyzz<F> acc;
@@ -431,6 +426,43 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     const bool ends_inside = next <= end;
     u32 *dst = (starts_inside && ends_inside) ? bw + (u64)b * PW : (starts_inside ? pw + PW : pw);
     store_xyzz<F>(dst, acc);
+}
+
+// PERSIST: the grid is a fixed number of workgroups (a few per CU) whose threads walk the chunks t, t + threads, ... -- the launch
+// that runs BESIDE the sort of the rest of the list: three of its waves per SIMD keep the vector pipe as good as full and leave a
+// quarter of the register file and all of the LDS to the sort's workgroups on the other stream (a grid of one thread per chunk fills
+// every wave slot for as long as it has chunks left, and the other stream's workgroups wait).
+template <class F, bool PERSIST>
+__global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
+                                                    u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
+                                                    unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale, AccPart part)
+{
+    constexpr int PW = 4 * F::N;
+    const unsigned w = blockIdx.y;
+    const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 == 0) long_count[w] = 0; // the fix-up's queue of long buckets starts empty (it runs behind this kernel on the same stream)
+    // the registered buffer no longer holds what was registered (the digits kernel of this range found out): the call will be repeated
+    // from the caller's buffer, and nine tenths of the work it would waste are in this kernel
+    if (stale && *stale) return;
+    const u32 *ow = off + (u64)w * (NB + 1);
+    const u32 lo_pos = part.pos ? part.pos[part.lo] : 0u;
+    const u32 limit = part.pos ? part.pos[part.hi] : ow[NB]; // pos[cells] is the number of entries, too
+    const unsigned search_hi = part.pos ? part.hi_bucket : NB;
+    const bool takes_short_chunk = part.pos ? part.last != 0 : true;
+    const u32 *sw = sorted + (u64)w * stride;
+    u32 *bw = bucket_acc + (u64)w * NB * PW;
+#pragma unroll 1
+    for (unsigned t = t0; t < chunks; t += gridDim.x * blockDim.x) {
+        const u32 start = t * K;
+        if (start >= limit) return;
+        u32 end = start + K;
+        if (end > limit) {
+            if (!takes_short_chunk) return; // ends among entries a later launch owns
+            end = limit;
+        }
+        if (end > lo_pos) accumulate_chunk<F>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end);
+        if (!PERSIST) return;
+    }
 }
 
 // bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
@@ -869,6 +901,40 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     const size_t sort_mark[2] = {arena.used, arena.used + panda::align256(sz_sort) + 512}; // a lane's sorts carve their scratch from its mark again
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
+    // One call, whole input at once, with tables: levels 2 and 3 of the sort for the rest of the bucket space run on the helper stream
+    // beside the accumulation of the front (SortSplit, msm_sort.h).  The three ordering events live as long as the host thread.
+    struct SplitEvents {
+        hipEvent_t ev[3] = {};
+        int device = -1;
+        void drop()
+        {
+            for (auto &e : ev) {
+                if (e) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        }
+        ~SplitEvents() { drop(); }
+    };
+    static thread_local SplitEvents split_events;
+    panda::SortSplit split{};
+    const bool want_split = tabled && nranges == 1 && tuning.overlap_front != 0 && tuning.overlap_front < 128;
+    // workgroups per CU of the accumulation that runs beside the sort: one wave per SIMD fewer than the kernel's own occupancy for the
+    // 9-limb fields (4 x 128 registers fill the file); the 14-limb fields run two waves of ~176 registers anyway, which already leaves room
+    const unsigned overlap_wgs = tuning.overlap_wgs ? tuning.overlap_wgs : (Fq::N <= 9 ? 6u : 4u);
+    if (want_split) {
+        int dev = -1;
+        PANDA_TRY(hipGetDevice(&dev));
+        if (split_events.device != dev) {
+            split_events.drop();
+            for (auto &e : split_events.ev) PANDA_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            split_events.device = dev;
+        }
+        PANDA_TRY(panda::thread_helper_stream(&split.helper));
+        split.front_of_128 = tuning.overlap_front;
+        split.ev_level1 = split_events.ev[0];
+        split.ev_front = split_events.ev[1];
+        split.rest_done = split_events.ev[2];
+    }
 
     struct PhaseEvents { // the per-range events are destroyed on every exit path
         std::vector<hipEvent_t> uploaded, fixed; // range r: its scalars have arrived / its buckets are in the total
@@ -950,7 +1016,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         const panda::SortPlacement place{nranges > 1 ? log_n : 0u, (uint32_t)row0};
         const void *scalars_r = (const char *)cfg.scalars + row0 * 32;
         if (tabled)
-            PANDA_TRY(panda::msm_sort_tabled(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place, sample_check));
+            PANDA_TRY(panda::msm_sort_tabled(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place, sample_check, want_split ? &split : nullptr));
         else
             PANDA_TRY(panda::msm_sort_plain(ls, arena, curve, scalars_r, log_c, plan, sort_events, &sorted, place, sample_check));
         if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
@@ -962,8 +1028,19 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         u32 *d_parts = d_parts_l[lane], *d_lcount = d_lcount_l[lane], *d_llist = d_llist_l[lane];
         // (no zero-fill of the bucket array: the first range's fix-up writes the identity into its empty buckets; k_accumulate empties the
         // fix-up's queue of long buckets)
-        hipLaunchKernelGGL(k_accumulate<Fq>, dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
-                           NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr);
+        if (split.active) {
+            // the front of the list, in a grid small enough to leave room on every CU, while the helper stream sorts the rest; then the rest
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, registration->device);
+            const unsigned persist_wgs = std::min((unsigned)cus * overlap_wgs, (g.chunks + 127) / 128);
+            hipLaunchKernelGGL((k_accumulate<Fq, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K, g.chunks,
+                               d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, 0u, split.cut_cell, 0u, split.cut_bucket});
+            PANDA_TRY(hipStreamWaitEvent(ls, split.rest_done, 0));
+            hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
+                               g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB});
+        } else
+            hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
+                               NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB});
         if (last && wanted(4)) PANDA_TRY(hipEventRecord(ev[4], ls));
         // 256-thread workgroups: at 2^16 buckets that is one per CU, a wave per SIMD (with 128 the dispatcher doubled them up on half
         // the CUs and every addition took 1.6x as long: fix-up 0.225 -> 0.162 ms at 2^20 points)

@@ -58,11 +58,27 @@ size_t msm_sort_plain_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
                           SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{});
 
+// Overlap of the sort's back half with the accumulation (tabled mode; replaces the serial phases of msm_cuda.cuh:611-755).  Level 1
+// partitions every window's entries by the TOP bits of the bucket id, so everything behind it -- level 2, level 3, k_accumulate -- can
+// run per range of level-1 partitions: the buckets are cut at a partition boundary into a FRONT part and the REST.  The front's levels
+// 2 and 3 run on the caller's stream, the rest's on `helper` beside whatever the caller enqueues behind the sort (the accumulation of the
+// front), and `rest_done` is recorded on `helper` when the whole list is sorted.  The entries before pos[cut_cell] and the bucket
+// offsets up to and including off[cut_bucket] are final in the caller's stream order when msm_sort_tabled returns.
+struct SortSplit {
+    hipStream_t helper;          // in: second stream (nullptr: no split)
+    unsigned front_of_128;       // in: size of the front part, in 1/128 of the bucket space (rounded to what the geometry allows)
+    hipEvent_t ev_level1, ev_front, rest_done; // in: three events the caller owns (no timing needed)
+    bool active;                 // out: the sort was split (false: sizes too small for it; everything ran on the caller's stream)
+    const uint32_t *pos;         // out: position of every level-3 cell's first entry in the list, pos[cells] = number of entries
+    unsigned cells, cut_cell;    // out: cells in all, first cell of the rest
+    unsigned cut_bucket;         // out: first bucket of the rest
+};
+
 // Tabled mode: one list over all windows; entry index = k * n + i names row i of table k (= 2^lo[k] * base i), so
 // every window falls into the same 2^(c-1) buckets and the window sums need no Horner step.
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan);
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{});
+                           SortResult *out, SortPlacement place = SortPlacement{0, 0}, SampleCheck check = SampleCheck{}, SortSplit *split = nullptr);
 
 } // namespace panda

@@ -462,9 +462,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k_bucket_sort(const u32 *__restr
 }
 
 // ---- tabled mode, level 2: ragged segments ---------------------------------------------------------------------------
-// Segment s = k * H1 + h1 is level-1 partition h1 of window k: positions [k*n + part_off[k][h1], k*n + part_off[k][h1+1])
+// Segment s = h1 * W + k is level-1 partition h1 of window k: positions [k*n + part_off[k][h1], k*n + part_off[k][h1+1])
 // of p1.  Its tiles are numbered seg_tile[s] .. seg_tile[s+1]-1; the launch covers an upper bound of tiles and a
-// workgroup finds its segment by binary search.
+// workgroup finds its segment by binary search.  Segments are numbered partition-major so that a RANGE of level-1 partitions
+// -- a contiguous range of buckets -- is a contiguous range of segments, of tiles and of level-3 cells: levels 2 and 3 can then
+// run for the front of the bucket space and for the rest in separate launches (SortSplit, msm_sort.h).
 
 struct TabledGeom {
     unsigned log_n, W;
@@ -477,6 +479,12 @@ struct TabledGeom {
     unsigned per_window; // 0: one list, level 3 merges the W windows of a cell (tabled mode);  1: W lists, a level-3 cell is one window's
                          // (plain mode with windows too wide for the two-level sort): cells are numbered window-major, entries name row0 + i
 };
+__host__ __device__ __forceinline__ unsigned seg_of(const TabledGeom &g, unsigned k, unsigned h1) { return h1 * g.W + k; }
+
+// what one launch of the level-2 / level-3 kernels covers: segments [s_lo, s_hi), cells [q_lo, q_hi) (q_lo a multiple of 1024)
+struct SortRange {
+    unsigned s_lo, s_hi, q_lo, q_hi;
+};
 
 // one workgroup: seg_tile[0..S] = exclusive prefix of ceil(len_s / SORT_TILE)
 __global__ void __launch_bounds__(SORT_THREADS) k2_seg_tiles(const u32 *__restrict__ part_off, u32 *__restrict__ seg_tile, TabledGeom g)
@@ -488,7 +496,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_seg_tiles(const u32 *__restri
     for (unsigned j = 0; j < per; j++) {
         unsigned s = tid * per + j;
         if (s < g.S) {
-            unsigned k = s / g.H1, h1 = s % g.H1;
+            unsigned k = s % g.W, h1 = s / g.W;
             const u32 *po = part_off + (u64)k * (g.H1 + 1);
             local += (po[h1 + 1] - po[h1] + SORT_TILE - 1) / SORT_TILE;
         }
@@ -505,7 +513,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_seg_tiles(const u32 *__restri
     for (unsigned j = 0; j < per; j++) {
         unsigned s = tid * per + j;
         if (s < g.S) {
-            unsigned k = s / g.H1, h1 = s % g.H1;
+            unsigned k = s % g.W, h1 = s / g.W;
             const u32 *po = part_off + (u64)k * (g.H1 + 1);
             seg_tile[s] = run;
             run += (po[h1 + 1] - po[h1] + SORT_TILE - 1) / SORT_TILE;
@@ -520,18 +528,20 @@ struct TileRange {
     u64 seg_begin;
 };
 
-// tile -> (segment, range); false if the tile index is beyond the last tile (uniform over the workgroup)
-__device__ __forceinline__ bool locate_tile(TileRange &r, unsigned tile, const u32 *seg_tile, const u32 *part_off, const TabledGeom &g)
+// workgroup `rel` of a launch over the segments [R.s_lo, R.s_hi) -> (tile, segment, range); false if the launch has more workgroups
+// than the range has tiles (uniform over the workgroup)
+__device__ __forceinline__ bool locate_tile(TileRange &r, unsigned &tile, unsigned rel, const u32 *seg_tile, const u32 *part_off, const TabledGeom &g, const SortRange &R)
 {
-    if (tile >= seg_tile[g.S]) return false;
-    unsigned lo = 0, hi = g.S; // invariant: seg_tile[lo] <= tile < seg_tile[hi]
+    tile = seg_tile[R.s_lo] + rel;
+    if (tile >= seg_tile[R.s_hi]) return false;
+    unsigned lo = R.s_lo, hi = R.s_hi; // invariant: seg_tile[lo] <= tile < seg_tile[hi]
     while (hi - lo > 1) {
         unsigned mid = (lo + hi) >> 1;
         if (seg_tile[mid] <= tile) lo = mid;
         else hi = mid;
     }
     r.s = lo;
-    const unsigned k = lo / g.H1, h1 = lo % g.H1;
+    const unsigned k = lo % g.W, h1 = lo / g.W;
     const u32 *po = part_off + (u64)k * (g.H1 + 1);
     r.seg_begin = ((u64)k << g.log_n) + po[h1];
     const u64 seg_end = ((u64)k << g.log_n) + po[h1 + 1];
@@ -541,12 +551,13 @@ __device__ __forceinline__ bool locate_tile(TileRange &r, unsigned tile, const u
 }
 
 __global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
-                                               u32 *__restrict__ tile_hist, TabledGeom g)
+                                               u32 *__restrict__ tile_hist, TabledGeom g, SortRange R)
 {
     __shared__ u32 h[256];
-    const unsigned tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
+    unsigned tile;
     TileRange r;
-    if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
+    if (!locate_tile(r, tile, blockIdx.x, seg_tile, part_off, g, R)) return;
     h[tid] = 0;
     __syncthreads();
     // 16 entries per load: aligned 16-byte vectors from the vector that contains `begin` on; bytes outside the tile are
@@ -567,9 +578,9 @@ __global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__
 
 // one WAVE per (segment, h2) column: exclusive prefix over the segment's tiles (tile_pref), column total to totals[s][h2]
 __global__ void __launch_bounds__(1024) k2_scan_cols(const u32 *__restrict__ tile_hist, u32 *__restrict__ tile_pref, const u32 *__restrict__ seg_tile,
-                                                     u32 *__restrict__ totals, TabledGeom g)
+                                                     u32 *__restrict__ totals, TabledGeom g, SortRange R)
 {
-    const unsigned s = blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const unsigned s = R.s_lo + blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
     if (h >= g.H2) return; // whole wave exits together
     const unsigned t_begin = seg_tile[s], t_end = seg_tile[s + 1];
     u32 run = 0;
@@ -588,10 +599,10 @@ __global__ void __launch_bounds__(1024) k2_scan_cols(const u32 *__restrict__ til
 }
 
 // one block per segment: sub_off[s][0..H2] = exclusive scan of the column totals (relative to the segment start)
-__global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals, u32 *__restrict__ sub_off, TabledGeom g)
+__global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals, u32 *__restrict__ sub_off, TabledGeom g, SortRange R)
 {
     __shared__ u32 tot[256];
-    const unsigned s = blockIdx.x, t = threadIdx.x;
+    const unsigned s = R.s_lo + blockIdx.x, t = threadIdx.x;
     const u32 mine = t < g.H2 ? totals[(u64)s * g.H2 + t] : 0;
     tot[t] = mine;
     __syncthreads();
@@ -608,16 +619,17 @@ __global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals
 // level-2 scatter: the u32 halves of the level-1 words, grouped by their u8 halves within the segment
 __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict__ p1_lo, const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off,
                                                   const u32 *__restrict__ seg_tile, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
-                                                  const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g)
+                                                  const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g, SortRange R)
 {
     __shared__ u32 lstart[256], lcur[256];
     __shared__ u64 gbase[256];
     __shared__ u32 words[SORT_TILE];
     __shared__ unsigned char parts_of[SORT_TILE];
     __shared__ u32 scratch[SORT_THREADS];
-    const unsigned tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
+    unsigned tile;
     TileRange r;
-    if (!locate_tile(r, tile, seg_tile, part_off, g)) return;
+    if (!locate_tile(r, tile, blockIdx.x, seg_tile, part_off, g, R)) return;
     if (tid < 256) {
         lstart[tid] = tid < g.H2 ? tile_hist[(u64)tile * g.H2 + tid] : 0;
         lcur[tid] = 0;
@@ -661,7 +673,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
 
 __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsigned h1, unsigned h2, const u32 *part_off, const u32 *sub_off, const TabledGeom &g)
 {
-    const unsigned s = k * g.H1 + h1;
+    const unsigned s = seg_of(g, k, h1);
     const u32 *so = sub_off + (u64)s * (g.H2 + 1);
     begin = ((u64)k << g.log_n) + part_off[(u64)k * (g.H1 + 1) + h1] + so[h2];
     len = so[h2 + 1] - so[h2];
@@ -670,17 +682,17 @@ __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsig
 // cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b.  per_window: cell q = k * Q + (h1 * H2 + h2)
 __device__ __forceinline__ unsigned cells_total(const TabledGeom &g) { return g.per_window ? g.W * g.Q : g.Q; }
 
-__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g)
+__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g, SortRange R)
 {
     __shared__ u32 red[1024];
-    const unsigned q = blockIdx.x * 1024 + threadIdx.x, t = threadIdx.x;
+    const unsigned blk = R.q_lo / 1024 + blockIdx.x, q = blk * 1024 + threadIdx.x, t = threadIdx.x;
     u32 total = 0;
-    if (q < cells_total(g)) {
+    if (q < R.q_hi) {
         const unsigned cell = g.per_window ? q % g.Q : q;
         const unsigned h1 = cell / g.H2, h2 = cell % g.H2;
         const unsigned k_begin = g.per_window ? q / g.Q : 0u, k_end = g.per_window ? k_begin + 1 : g.W;
         for (unsigned k = k_begin; k < k_end; k++) {
-            const u32 *so = sub_off + (u64)(k * g.H1 + h1) * (g.H2 + 1);
+            const u32 *so = sub_off + (u64)seg_of(g, k, h1) * (g.H2 + 1);
             total += so[h2 + 1] - so[h2];
         }
         cell_cnt[q] = total;
@@ -691,20 +703,19 @@ __global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ s
         if (t < s) red[t] += red[t + s];
         __syncthreads();
     }
-    if (t == 0) blk_sum[blockIdx.x] = red[0];
+    if (t == 0) blk_sum[blk] = red[0];
 }
 
 // cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block
-__global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ cell_off, TabledGeom g)
+__global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ cell_off, TabledGeom g, SortRange R)
 {
     __shared__ u32 red[1024];
     __shared__ u32 sc[1024];
-    const unsigned blk = blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
-    const unsigned Qt = cells_total(g);
+    const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
     u32 v = 0;
-    for (unsigned b = t; b < blk; b += 1024) v += blk_sum[b];
+    for (unsigned b = t; b < blk; b += 1024) v += blk_sum[b]; // the blocks of earlier launches included: their counts are complete (stream / event order)
     red[t] = v;
-    const u32 mine = q < Qt ? cell_cnt[q] : 0;
+    const u32 mine = q < R.q_hi ? cell_cnt[q] : 0;
     sc[t] = mine;
     __syncthreads();
     for (unsigned s = 512; s > 0; s >>= 1) {
@@ -717,8 +728,8 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
         sc[t] += u;
         __syncthreads();
     }
-    if (q < Qt) cell_off[q] = red[0] + sc[t] - mine;
-    if (q == Qt - 1) cell_off[Qt] = red[0] + sc[t];
+    if (q < R.q_hi) cell_off[q] = red[0] + sc[t] - mine;
+    if (q == R.q_hi - 1) cell_off[R.q_hi] = red[0] + sc[t]; // the start of the next launch's first cell (written again, to the same value, by that launch); the list's total at the end
 }
 
 constexpr unsigned K3_THREADS = 1024;
@@ -726,7 +737,7 @@ constexpr unsigned K3_PER = 16;                     // words a thread keeps in r
 constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once
 
 __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
-                                              const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB)
+                                              const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
 {
     __shared__ u32 cnt[128], cur[128], scan_carry;
     __shared__ u32 outbuf[K3_CAP];
@@ -735,12 +746,16 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     __shared__ u32 vstart[65];
     const unsigned tid = threadIdx.x;
     // tabled mode: cell q of the one list, W runs to merge;  per-window mode: cell q of window k0's own list, one run
-    const unsigned k0 = g.per_window ? blockIdx.x / g.Q : 0u, q = g.per_window ? blockIdx.x % g.Q : blockIdx.x;
+    const unsigned cell = R.q_lo + blockIdx.x;
+    const unsigned k0 = g.per_window ? cell / g.Q : 0u, q = g.per_window ? cell % g.Q : cell;
     const unsigned nruns = g.per_window ? 1u : g.W;
     const unsigned h1 = q / g.H2, h2 = q % g.H2;
     const unsigned L = 1u << g.b3;
     // position of the cell's first entry within its list, and where the list starts in `sorted` / `off`
-    const u32 out_rel = cell_off[blockIdx.x] - (g.per_window ? cell_off[k0 * g.Q] : 0u);
+    const u32 out_rel = cell_off[cell] - (g.per_window ? cell_off[k0 * g.Q] : 0u);
+    // the last cell of a launch that stops short of the list's end also publishes where the NEXT cell's first bucket starts: the
+    // accumulation of this launch's part reads off[b + 1] of its last bucket before the launch that owns that cell has run
+    const bool closes_part = !g.per_window && cell + 1 == R.q_hi && q + 1 < g.Q;
     u32 *sw = sorted + ((u64)k0 << g.log_n);
     u32 *ow = off + (u64)k0 * (NB + 1);
     if (tid < nruns) {
@@ -776,6 +791,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         return ((v & id_mask) + g.row0 + (table_shift < 32 ? (k << table_shift) : 0u)) | (((v >> g.log_n) & 1u) << 31);
     };
 
+    if (closes_part && tid == 0) ow[(u64)(q + 1) << g.b3] = out_rel + N;
     if (N == 0) { // an empty cell: its buckets all start where the cell does
         if (tid < L) ow[((u64)q << g.b3) + tid] = out_rel;
         if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel;
@@ -980,7 +996,7 @@ WindowPlan make_safe_window_plan(unsigned fr, unsigned c) { return fr == 0 ? saf
 static bool sort3_supported(unsigned log_n, const WindowPlan &plan, bool per_window);
 static size_t sort3_bytes(unsigned log_n, const WindowPlan &plan, bool per_window);
 static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev, SortResult *out,
-                        SortPlacement place, SampleCheck check, bool per_window);
+                        SortPlacement place, SampleCheck check, bool per_window, SortSplit *split = nullptr);
 
 bool msm_sort_plain_supported(unsigned log_n, const WindowPlan &plan)
 {
@@ -1067,7 +1083,7 @@ static size_t sort3_bytes(unsigned log_n, const WindowPlan &plan, bool per_windo
 
 // the three-level sort: tabled mode (one list over all windows) or per-window mode (W lists)
 static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev, SortResult *out,
-                        SortPlacement place, SampleCheck check, bool per_window)
+                        SortPlacement place, SampleCheck check, bool per_window, SortSplit *split)
 {
     if (!sort3_supported(log_n, plan, per_window)) return hipErrorInvalidValue;
     const u64 n = (u64)1 << log_n;
@@ -1120,17 +1136,59 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     hipLaunchKernelGGL(k_part_scan_cols, dim3((g1.H + 15) / 16, W), dim3(1024), 0, stream, d_thist1, d_tpref1, d_ptot, g1);
     hipLaunchKernelGGL(k_part_offsets, dim3(W), dim3(1024), 0, stream, d_ptot, d_poff, g1);
     hipLaunchKernelGGL(k1_scatter_split<u32>, dim3(g1.tiles, W), dim3(SORT_THREADS), 0, stream, d_dig, d_thist1, d_tpref1, d_poff, d_p1_lo, d_p1_hi, g1, g.b3);
-    // level 2, per level-1 partition
     hipLaunchKernelGGL(k2_seg_tiles, dim3(1), dim3(SORT_THREADS), 0, stream, d_poff, d_segtile, g);
-    hipLaunchKernelGGL(k2_hist, dim3(g.max_tiles2), dim3(256), 0, stream, d_p1_hi, d_poff, d_segtile, d_thist2, g);
-    hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, g.S), dim3(1024), 0, stream, d_thist2, d_tpref2, d_segtile, d_tot2, g);
-    hipLaunchKernelGGL(k2_offsets, dim3(g.S), dim3(256), 0, stream, d_tot2, d_suboff, g);
-    hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, stream, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g);
-    if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
-    // level 3, per cell
-    hipLaunchKernelGGL(k3_cell_counts, dim3(qblocks), dim3(1024), 0, stream, d_suboff, d_cellcnt, d_blksum, g);
-    hipLaunchKernelGGL(k3_cell_offsets, dim3(qblocks), dim3(1024), 0, stream, d_cellcnt, d_blksum, d_celloff, g);
-    hipLaunchKernelGGL(k3_merge, dim3(cells), dim3(K3_THREADS), 0, stream, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB);
+    // Levels 2 and 3 for the level-1 partitions [h1_lo, h1_hi) -- a contiguous range of segments, tiles, cells and buckets -- on stream s.
+    // The launch bound of the tile kernels is the whole list's (how the entries spread over the partitions is the scalars' business);
+    // workgroups beyond the range's last tile leave after two loads.
+    auto level2 = [&](hipStream_t s, const SortRange &R) {
+        hipLaunchKernelGGL(k2_hist, dim3(g.max_tiles2), dim3(256), 0, s, d_p1_hi, d_poff, d_segtile, d_thist2, g, R);
+        hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, R.s_hi - R.s_lo), dim3(1024), 0, s, d_thist2, d_tpref2, d_segtile, d_tot2, g, R);
+        hipLaunchKernelGGL(k2_offsets, dim3(R.s_hi - R.s_lo), dim3(256), 0, s, d_tot2, d_suboff, g, R);
+        hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
+    };
+    auto level3_counts = [&](hipStream_t s, const SortRange &R) {
+        hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
+    };
+    auto level3_merge = [&](hipStream_t s, const SortRange &R) {
+        hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
+        hipLaunchKernelGGL(k3_merge, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
+    };
+    // the cut between the front and the rest: a level-1 partition boundary whose first cell starts a block of 1024 cells
+    unsigned cut_h1 = 0;
+    if (split) {
+        split->active = false;
+        const unsigned step = g.H2 >= 1024 ? 1u : 1024u / g.H2; // partitions per block of cells
+        if (split->helper && !per_window && split->front_of_128 && g.H1 >= 2 * step && g.Q % 1024 == 0) {
+            cut_h1 = (unsigned)(((u64)g.H1 * split->front_of_128 / 128 + step / 2) / step * step);
+            cut_h1 = std::min(std::max(cut_h1, step), g.H1 - step);
+        }
+    }
+    if (cut_h1) {
+        const SortRange front{0, cut_h1 * W, 0, cut_h1 * g.H2}, rest{cut_h1 * W, g.S, cut_h1 * g.H2, g.Q};
+        level2(stream, front);
+        if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
+        level3_counts(stream, front);
+        level3_merge(stream, front);
+        // the rest starts when the front is sorted, beside whatever the caller enqueues next (started earlier it shares the chip with the
+        // front's own levels 2 and 3, which are on the critical path: 1.6 ms instead of 0.4 at 2^24)
+        PANDA_TRY(hipEventRecord(split->ev_front, stream));
+        PANDA_TRY(hipStreamWaitEvent(split->helper, split->ev_front, 0));
+        level2(split->helper, rest);
+        level3_counts(split->helper, rest); // its cell offsets continue the front's block sums (complete: ev_front)
+        level3_merge(split->helper, rest);
+        PANDA_TRY(hipEventRecord(split->rest_done, split->helper));
+        split->active = true;
+        split->pos = d_celloff;
+        split->cells = g.Q;
+        split->cut_cell = cut_h1 * g.H2;
+        split->cut_bucket = split->cut_cell << g.b3;
+    } else {
+        const SortRange all{0, g.S, 0, cells};
+        level2(stream, all);
+        if (ev.partition_done) PANDA_TRY(hipEventRecord(ev.partition_done, stream));
+        level3_counts(stream, all);
+        level3_merge(stream, all);
+    }
     out->off = d_off;
     out->sorted = d_sorted;
     out->lists = lists;
@@ -1143,9 +1201,9 @@ bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan) { return 
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan) { return sort3_bytes(log_n, plan, false); }
 
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
-                           SortResult *out, SortPlacement place, SampleCheck check)
+                           SortResult *out, SortPlacement place, SampleCheck check, SortSplit *split)
 {
-    return sort3(stream, arena, fr, scalars, log_n, plan, ev, out, place, check, false);
+    return sort3(stream, arena, fr, scalars, log_n, plan, ev, out, place, check, false, split);
 }
 
 } // namespace panda

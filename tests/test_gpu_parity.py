@@ -1289,6 +1289,51 @@ def test_msm_precomputed_tables_skewed_2_15(gm, kind):
     assert (affine_of(0, out) == po.expected_from_linearity(0, 56, scalars)).all()
 
 
+@pytest.mark.parametrize("cid,k,wbits,front,wgs,kind", [
+    (0, 13, 19, 64, 6, "uniform"), (0, 15, 20, 32, 4, "uniform"), (0, 16, 22, 8, 6, "uniform"), (0, 16, 22, 120, 2, "uniform"), (0, 14, 21, 1, 64, "uniform"),
+    (0, 14, 22, 40, 6, "zeros"), (0, 14, 22, 40, 6, "ones"), (0, 14, 22, 40, 6, "minus_one"), (0, 14, 22, 40, 6, "small"), (0, 14, 22, 40, 6, "all_equal"),
+    (0, 14, 22, 40, 6, "half_zero"), (0, 14, 22, 40, 6, "top_bit"), (0, 18, 22, 32, 6, "uniform"), (0, 20, 0, 32, 6, "uniform"), (1, 14, 20, 32, 0, "uniform"),
+    (2, 13, 19, 64, 0, "uniform")])
+def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, wbits, front, wgs, kind):
+    """panda_msm_set_overlap: with tables, levels 2 and 3 of the sort for the back of the bucket space run on a second stream beside the
+    accumulation of the front (a launch of a few workgroups per CU), then the rest is accumulated.  Same group element as the oracle
+    says and as the one-stream schedule returns (not byte for byte: the order of a bucket's entries, and with it the Jacobian
+    representative, follows the merge kernel's LDS atomics from run to run): for every way the entries can fall on the two sides of
+    the cut -- uniform, everything in a handful of buckets, nothing at all."""
+    lib = ffi.load()
+    n = 1 << k
+    lq = po.LC_Q[cid]
+    db, ds, dr = DeviceBuffer(n * 2 * lq * 4), DeviceBuffer(n * 32), DeviceBuffer(3 * lq * 4)
+    seed_b = 0x0E11A9 + 31 * k + cid
+    ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    if kind == "uniform":
+        ffi.check(lib.panda_gen_scalars(cid, 0x5CA1AB + k, 0, n, ds.ptr, NULL_STREAM), "gen")
+    else:
+        ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(np.ascontiguousarray(_edge_scalars(kind, n)).ctypes.data), n * 32), "memcpy")
+    scalars = ds.to_host().reshape(n, 8)
+    ffi.check(lib.panda_msm_precompute_bases(cid, db.ptr, k, wbits, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[cid]
+    try:
+        ffi.check(lib.panda_msm_set_overlap(0, 0), "set_overlap")
+        ffi.check(fn(cfg), "msm")
+        serial = dr.to_host().copy()
+        ffi.check(lib.panda_msm_set_overlap(front, wgs), "set_overlap")
+        for _ in range(2):  # the second call meets the first one's offsets and cell positions in the arena
+            ffi.check(lib.panda_memset(dr.ptr, 0, 3 * lq * 4), "memset")
+            ffi.check(fn(cfg), "msm")
+            split = dr.to_host().copy()
+            assert (po.to_affine(cid, split) == po.to_affine(cid, serial)).all()
+    finally:
+        lib.panda_msm_set_overlap(0xFFFFFFFF, 0)
+        lib.panda_msm_unregister_bases(db.ptr)
+    assert (ds.to_host().reshape(n, 8) == scalars).all()
+    assert (po.to_affine(cid, split) == po.expected_from_linearity(cid, seed_b, scalars)).all()
+    assert lib.panda_msm_set_overlap(128, 0) != 0 and lib.panda_msm_set_overlap(1, 65) != 0
+    for d in (db, ds, dr):
+        d.free()
+
+
 @pytest.mark.parametrize("kind", ["all_equal", "half_zero", "three_values", "all_equal_from_host_5_ranges"])
 def test_msm_skewed_scalars_full_size_2_22(gm, kind):
     """Skew at a size where it bites: 2^22 points with precomputed tables.  Equal scalars put 2^22 entries into ONE bucket per window
