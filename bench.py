@@ -711,6 +711,8 @@ def main():
         leg("msm_2_22", lambda: small_config(ctx, 0, 22, ctx.ffi.JACOBIAN, 10, "BN254 MSM 2^22, Jacobian output, cached bases (north_star sweep 2^20 ... 2^26)"))
     if world == 1 and not args.no_ntt:
         leg("ntt", lambda: ntt_figure(ctx, sweep=not args.no_ntt_sweep))  # BASELINE config 3, also millisecond-sized: before the heavy legs, for the same reason
+        if not args.no_ntt_sweep:
+            leg("ntt_bls12_377", lambda: ntt_figure(ctx, sweep=False, field=1))
     if world == 1 and not args.no_compare:
         leg("pcie_inclusive", lambda: pcie_inclusive(ctx, prob))
         if prob.tables > 1:
@@ -882,14 +884,15 @@ def pcie_inclusive(ctx: Ctx, prob: MsmProblem) -> dict:
     return out
 
 
-def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
-    """forward and inverse BN254 NTT of 2^log_n device-resident elements: 3 warm-up calls, median of `reps`"""
+def ntt_one(ctx: Ctx, log_n: int, reps: int, field: int = 0) -> dict:
+    """forward and inverse NTT of 2^log_n device-resident elements over BN254 Fr (field 0) or BLS12-377 Fr (field 1): warm-up calls,
+    then the median of `reps`"""
     torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
     n = 1 << log_n
     a = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
     b = torch.empty(n * 32, dtype=torch.uint8, device=ctx.dev)
-    ffi.check(lib.panda_gen_scalars(0, 0x4E5454, 0, n, a.data_ptr(), ctx.pstream), "gen")
-    omega = _root_of_unity_host(log_n)
+    ffi.check(lib.panda_gen_scalars(field, 0x4E5454, 0, n, a.data_ptr(), ctx.pstream), "gen")
+    omega = _root_of_unity_host(log_n, field)
     flag = C.c_uint(0)
     cfg = ffi.NttconfigurationV1(ffi.PandaMemPool(), ctx.pstream, a.data_ptr(), b.data_ptr(), C.c_void_p(omega.ctypes.data), log_n, C.pointer(flag))
 
@@ -916,8 +919,8 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
         wall_ts.sort()
         return dev_ts[len(dev_ts) // 2], wall_ts[len(wall_ts) // 2]
 
-    fwd, fwd_wall = timed(lib.panda_ntt_execute_bn254_v1)
-    inv, inv_wall = timed(lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
+    fwd, fwd_wall = timed(lib.panda_ntt_execute_bls12_377_v1 if field else lib.panda_ntt_execute_bn254_v1)
+    inv, inv_wall = timed(lib.panda_ntt_execute_bls12_377_inverse if field else lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
     passes, bits = C.c_uint(0), (C.c_uint * 4)()
     ffi.check(lib.panda_ntt_pass_plan(log_n, C.byref(passes), bits), "ntt_plan")
@@ -930,11 +933,12 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int) -> dict:
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 
 
-def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True) -> dict:
-    """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26."""
-    res = ntt_one(ctx, log_n, reps)
+def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True, field: int = 0) -> dict:
+    """BASELINE config 3: BN254 NTT 2^24 forward and inverse, device-resident -- plus the north_star sweep 2^20 / 2^22 / 2^26; field = 1: the
+    same transform over the BLS12-377 scalar field (north_star: "NTT butterfly over BN254/BLS12-377"), 2^24 only."""
+    res = ntt_one(ctx, log_n, reps, field)
     n24 = 1 << log_n
-    res["metric"] = "NTT elements/s (BN254 Fr, 2^24, forward)"
+    res["metric"] = f"NTT elements/s ({'BLS12-377' if field else 'BN254'} Fr, 2^24, forward)"
     if log_n == 24:
         # what binds the passes (DESIGN.md section 5): v_mad_u64_u32 per thread (8 elements) and pass in k_ntt_pass8 -- 24.25 butterfly products
         # (7 of wave 0's 12 middle-block products are skipped) + 8 / 16 / 0 output products of 143 each -- over the transform's device time
@@ -945,7 +949,7 @@ def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True) ->
     res["timing"] = ("ms = device time of the passes (HIP events on the launch stream inside the library: first pass to result ready); "
                      "wall_ms = host time of the synchronous call; untimed warm-up calls for 40 ms (at least 3) carry the chip from idle to its sustained clock, then the median of 11")
     if sweep:
-        res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 11) for k in (20, 22, 26)}
+        res["sweep"] = {f"2^{k}": ntt_one(ctx, k, 11, field) for k in (20, 22, 26)}
     return res
 
 
@@ -990,14 +994,16 @@ def ntt_sharded_figure(ctx: Ctx, reps: int = 5) -> dict:
     return res
 
 
-def _root_of_unity_host(log_n):
-    """omega of order 2^log_n in wire form: 7^((r-1)/2^28) squared down (bn254/paramter.cuh:241-258), computed with
-    Python integers -- no oracle involved."""
+def _root_of_unity_host(log_n, field: int = 0):
+    """omega of order 2^log_n in wire form: BN254 Fr 7^((r-1)/2^28) squared down (bn254/paramter.cuh:241-258), BLS12-377 Fr
+    22^((r-1)/2^47) (two-adicity 47, bls12_377/paramter.cuh:130-181), computed with Python integers -- no oracle involved."""
     import numpy as np
 
-    r = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
-    w = pow(7, (r - 1) >> 28, r)
-    w = pow(w, 1 << (28 - log_n), r)
+    r, gen, adicity = ((0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 7, 28),
+                       (0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001, 22, 47))[field]
+    w = pow(gen, (r - 1) >> adicity, r)
+    w = pow(w, 1 << (adicity - log_n), r)
+    assert pow(w, 1 << log_n, r) == 1 and (log_n == 0 or pow(w, 1 << (log_n - 1), r) == r - 1)
     return np.frombuffer((w * (1 << 256) % r).to_bytes(32, "little"), dtype=np.uint32).copy()
 
 

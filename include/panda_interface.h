@@ -236,6 +236,12 @@ panda_error panda_ntt_execute_bn254_coset_inverse(const panda_ntt_configuration_
 /* The same transforms over the BLS12-377 scalar field (README.md:36: "easy to encapsulate ... BLS12-377 later") */
 panda_error panda_ntt_execute_bls12_377_v1(const panda_ntt_configuration_v1 exec_cfg);
 panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1 exec_cfg);
+/* ... in every variant the BN254 field has (north_star: "NTT butterfly over BN254/BLS12-377"; field parameters:
+ * src/cuda/core/curve/bls12_377/paramter.cuh:130-181): bit-reversed orderings and coset transforms, semantics as for the _bn254_ entry points */
+panda_error panda_ntt_execute_bls12_377_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_377_inverse_bitrev_in(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_377_coset(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
+panda_error panda_ntt_execute_bls12_377_coset_inverse(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
 panda_error panda_ntt_execute_bls12_381_v1(const panda_ntt_configuration_v1 exec_cfg);
 panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1 exec_cfg);
 
@@ -272,6 +278,11 @@ panda_error panda_ntt_slab_step2_bn254_enqueue(const panda_ntt_slab_configuratio
  * inverse transform).  cfg.omega is the FORWARD root.  Enqueued without waiting, flag valid on return. */
 panda_error panda_ntt_slab_inverse_step1_bn254_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_inverse_step2_bn254_enqueue(const panda_ntt_slab_configuration cfg);
+/* the four enqueued halves over the BLS12-377 scalar field */
+panda_error panda_ntt_slab_step1_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_inverse_step1_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_inverse_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
 
 /* Multi-GPU, ONE process (no reference counterpart: msm_cuda.cuh:554-555 pins device 0, wrapper.rs:38 opens one
  * device, binding.rs:54-56 only declares the peer-access symbols).  A panda_multi_gpu owns one host thread, one stream and -- with
@@ -318,6 +329,11 @@ panda_error panda_ntt_execute_bn254_inverse_multi(panda_multi_gpu mg, const pand
  * t - 1 compute.  Layouts, flags and results as `count` separate panda_ntt_execute_bn254[_inverse]_multi calls; one synchronisation at the end. */
 panda_error panda_ntt_execute_bn254_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* count x n_dev */, unsigned count);
 panda_error panda_ntt_execute_bn254_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count);
+/* the sharded transforms over the BLS12-377 scalar field */
+panda_error panda_ntt_execute_bls12_377_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* n_dev */);
+panda_error panda_ntt_execute_bls12_377_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
+panda_error panda_ntt_execute_bls12_377_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* count x n_dev */, unsigned count);
+panda_error panda_ntt_execute_bls12_377_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count);
 /* per-phase device times of rank's last MSM inside a *_multi call (the workers' panda_msm_last_phase_ms) */
 panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms /* PANDA_MSM_PHASES floats */);
 

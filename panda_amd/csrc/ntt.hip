@@ -1232,6 +1232,41 @@ panda_error panda_ntt_execute_bls12_377_inverse(const panda_ntt_configuration_v1
         ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
 }
 
+// ... in every variant the BN254 field has (north_star: "NTT butterfly over BN254 / BLS12-377"): bit-reversed orderings, coset
+// transforms and the two halves of the slab-sharded transform (panda_ntt_execute_bls12_377[_inverse]_multi composes them, multi_gpu.hip)
+panda_error panda_ntt_execute_bls12_377_bitrev_out(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false, false, true));
+}
+
+panda_error panda_ntt_execute_bls12_377_inverse_bitrev_in(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls377Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true, true, false));
+}
+
+panda_error panda_ntt_execute_bls12_377_coset(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bls377Fr>(cfg, shift, false));
+}
+
+panda_error panda_ntt_execute_bls12_377_coset_inverse(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bls377Fr>(cfg, shift, true));
+}
+
+panda_error panda_ntt_slab_step1_bls12_377_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bls377Fr>(cfg, false)); }
+panda_error panda_ntt_slab_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bls377Fr>(cfg, false)); }
+panda_error panda_ntt_slab_inverse_step1_bls12_377_enqueue(const panda_ntt_slab_configuration cfg)
+{
+    return static_cast<panda_error>(slab_step2<Bls377Fr>(cfg, false, true));
+}
+panda_error panda_ntt_slab_inverse_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg)
+{
+    return static_cast<panda_error>(slab_inverse_local<Bls377Fr>(cfg, false));
+}
+
 // BLS12-381 Fr (two-adicity 32)
 panda_error panda_ntt_execute_bls12_381_v1(const panda_ntt_configuration_v1 cfg)
 {

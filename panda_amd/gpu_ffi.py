@@ -86,6 +86,9 @@ ADDITIVE_SYMBOLS = [
     "panda_msm_execute_bn254_from_host_multi", "panda_msm_execute_bls12_377_from_host_multi",
     "panda_msm_execute_bls12_381_multi", "panda_msm_execute_bn254_g2_multi", "panda_msm_execute_bls12_381_from_host_multi", "panda_msm_execute_bn254_g2_from_host_multi",
     "panda_ntt_execute_bn254_multi", "panda_ntt_execute_bn254_inverse_multi", "panda_ntt_execute_bn254_multi_batch", "panda_ntt_execute_bn254_inverse_multi_batch", "panda_multi_gpu_last_phase_ms",
+    "panda_ntt_execute_bls12_377_bitrev_out", "panda_ntt_execute_bls12_377_inverse_bitrev_in", "panda_ntt_execute_bls12_377_coset", "panda_ntt_execute_bls12_377_coset_inverse",
+    "panda_ntt_slab_step1_bls12_377_enqueue", "panda_ntt_slab_step2_bls12_377_enqueue", "panda_ntt_slab_inverse_step1_bls12_377_enqueue", "panda_ntt_slab_inverse_step2_bls12_377_enqueue",
+    "panda_ntt_execute_bls12_377_multi", "panda_ntt_execute_bls12_377_inverse_multi", "panda_ntt_execute_bls12_377_multi_batch", "panda_ntt_execute_bls12_377_inverse_multi_batch",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
 
@@ -151,6 +154,13 @@ def load() -> C.CDLL:
         "panda_ntt_execute_bn254_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)], "panda_ntt_execute_bn254_inverse_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)],
         "panda_ntt_execute_bn254_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint], "panda_ntt_execute_bn254_inverse_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
         "panda_multi_gpu_last_phase_ms": [PandaMultiGpu, u, C.POINTER(C.c_float)],
+        "panda_ntt_execute_bls12_377_bitrev_out": [NttconfigurationV1], "panda_ntt_execute_bls12_377_inverse_bitrev_in": [NttconfigurationV1],
+        "panda_ntt_execute_bls12_377_coset": [NttconfigurationV1, vp], "panda_ntt_execute_bls12_377_coset_inverse": [NttconfigurationV1, vp],
+        "panda_ntt_slab_step1_bls12_377_enqueue": [NttSlabConfiguration], "panda_ntt_slab_step2_bls12_377_enqueue": [NttSlabConfiguration],
+        "panda_ntt_slab_inverse_step1_bls12_377_enqueue": [NttSlabConfiguration], "panda_ntt_slab_inverse_step2_bls12_377_enqueue": [NttSlabConfiguration],
+        "panda_ntt_execute_bls12_377_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)], "panda_ntt_execute_bls12_377_inverse_multi": [PandaMultiGpu, C.POINTER(NttSlabConfiguration)],
+        "panda_ntt_execute_bls12_377_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
+        "panda_ntt_execute_bls12_377_inverse_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

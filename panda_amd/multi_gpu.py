@@ -287,9 +287,9 @@ class MultiGpu:
         ffi.check(fn(self.handle, arr, hp, ranges, C.c_void_p(out.ctypes.data)), "SchedulingErr")
         return out
 
-    def ntt(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None):
-        """panda_ntt_execute_bn254[_inverse]_multi on device pointers slabs[d] / scratches[d]; returns the flags (1: rank d's output is in
-        scratches[d])."""
+    def ntt(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None, field: int = 0):
+        """panda_ntt_execute_{bn254,bls12_377}[_inverse]_multi (field 0 / 1) on device pointers slabs[d] / scratches[d]; returns the flags
+        (1: rank d's output is in scratches[d])."""
         assert len(slabs) == len(scratches) == self.n
         g = _log2_exact(self.n)
         om = np.ascontiguousarray(np.asarray(omega).view(np.uint32).reshape(-1))
@@ -297,12 +297,13 @@ class MultiGpu:
         cfgs = (ffi.NttSlabConfiguration * self.n)(*[
             ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[d]), C.c_void_p(scratches[d]), C.c_void_p(om.ctypes.data),
                                      log_n, g, d, C.pointer(flags[d])) for d in range(self.n)])
-        fn = self.lib.panda_ntt_execute_bn254_inverse_multi if inverse else self.lib.panda_ntt_execute_bn254_multi
+        fn = ((self.lib.panda_ntt_execute_bn254_multi, self.lib.panda_ntt_execute_bn254_inverse_multi),
+              (self.lib.panda_ntt_execute_bls12_377_multi, self.lib.panda_ntt_execute_bls12_377_inverse_multi))[field][1 if inverse else 0]
         ffi.check(fn(self.handle, cfgs), "SchedulingErr")
         return [f.value for f in flags]
 
-    def ntt_batch(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None):
-        """panda_ntt_execute_bn254[_inverse]_multi_batch: slabs[t][d] / scratches[t][d] are the device pointers of rank d of transform t; the exchange
+    def ntt_batch(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None, field: int = 0):
+        """panda_ntt_execute_{bn254,bls12_377}[_inverse]_multi_batch: slabs[t][d] / scratches[t][d] are the device pointers of rank d of transform t; the exchange
         of transform t overlaps the kernels of its neighbours.  Returns flags[t][d] (1: the output is in scratches[t][d])."""
         count = len(slabs)
         assert count >= 1 and len(scratches) == count and all(len(a) == self.n and len(b) == self.n for a, b in zip(slabs, scratches))
@@ -312,7 +313,8 @@ class MultiGpu:
         cfgs = (ffi.NttSlabConfiguration * (self.n * count))(*[
             ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[t][d]), C.c_void_p(scratches[t][d]), C.c_void_p(om.ctypes.data),
                                      log_n, g, d, C.pointer(flags[t][d])) for t in range(count) for d in range(self.n)])
-        fn = self.lib.panda_ntt_execute_bn254_inverse_multi_batch if inverse else self.lib.panda_ntt_execute_bn254_multi_batch
+        fn = ((self.lib.panda_ntt_execute_bn254_multi_batch, self.lib.panda_ntt_execute_bn254_inverse_multi_batch),
+              (self.lib.panda_ntt_execute_bls12_377_multi_batch, self.lib.panda_ntt_execute_bls12_377_inverse_multi_batch))[field][1 if inverse else 0]
         ffi.check(fn(self.handle, cfgs, count), "SchedulingErr")
         return [[f.value for f in row] for row in flags]
 

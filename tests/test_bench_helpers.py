@@ -1,8 +1,11 @@
 """bench.py's host-side helpers (no GPU): the reference-algorithm model behind `vs_reference_model`, the plain path's window count,
 and the argument surface the driver and the single-process mode rely on."""
 import importlib.util
+
 import os
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -122,3 +125,23 @@ def test_contract_line_fits_the_drivers_record():
     assert cm["c2_msm_2_20_tables"] == 1.45 and line["roofline"]["frac"] == 0.014 and line["cpu_baseline"]["kind"] == "port"
     assert line["broken_leg"]["error"].startswith("e") and line["failed_legs"] == ["x"]
     assert not any(isinstance(v, str) and len(v) > 200 for v in json.loads(text)["config"].values())
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_on_the_gpu_box():
+    """`python bench.py --gpus 2 ...` typed WITHOUT a launcher in front (the driver's N = 1 command with another N): one contract line under
+    7 KB, two ranks (gloo, both on device 0: the rehearsal of the N > 1 path on a one-GPU box), the sharded legs in configs_ms"""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-on-device0", "--steps", "1", "--warmup", "0",
+           "--log-n", "18", "--config4-total-log-n", "19", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert len(lines[0]) < 7000
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "launcher" not in line
+    for k in ("c4_msm_2_26_total", "ntt_sharded_2_24_total", "ntt_sharded_2_24_per_gpu", "c_abi_msm_2_24_per_gpu"):
+        assert line["configs_ms"].get(k, 0) > 0, (k, line["configs_ms"])

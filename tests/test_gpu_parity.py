@@ -472,25 +472,28 @@ def test_ntt_setup_then_execute(gm):
     assert (buf == po.ntt(fid, x, om, log_n)).all()
 
 
-def test_ntt_2_24_values_and_full_roundtrip(gm):
-    """BASELINE config 3 (2^24 forward + inverse) at full size (SURVEY 8d "correctness at sizes the CPU cannot reach"):
+@pytest.mark.parametrize("cid", [0, 1])
+def test_ntt_2_24_values_and_full_roundtrip(gm, cid):
+    """BASELINE config 3 (2^24 forward + inverse) at full size over BN254 Fr and over BLS12-377 Fr (north_star: "NTT butterfly over
+    BN254/BLS12-377"; SURVEY 8d "correctness at sizes the CPU cannot reach"):
       * forward VALUES: y[k] for k = 0, 1, n/2, n-1 and 8 seeded random k evaluated directly from the definition
         y[k] = sum_j x[j] w^(jk) in O(n) each by the oracle (po_ntt_eval_at) and compared with the device output;
       * the forward transform of a delta x = e_j must be w^(jk): 64 random k against Python integers;
       * the WHOLE inverse(forward(x)) buffer equals x, compared byte for byte (2^24 x 32 B), not a sample."""
-    fid, log_n = po.F_BN254_FR, 24
+    fid, log_n = po.FR_OF[cid], 24
     n = 1 << log_n
     lib = ffi.load()
+    fwd_fn, inv_fn = ((lib.panda_ntt_execute_bn254_v1, lib.panda_ntt_execute_bn254_inverse), (lib.panda_ntt_execute_bls12_377_v1, lib.panda_ntt_execute_bls12_377_inverse))[cid]
     om = po.root_of_unity(fid, log_n)
-    c = pyref.CURVES[0]
-    rng = np.random.default_rng(0x24)
+    c = pyref.CURVES[cid]
+    rng = np.random.default_rng(0x24 + cid)
     d_a, d_b = DeviceBuffer(n * 32), DeviceBuffer(n * 32)
-    ffi.check(lib.panda_gen_scalars(0, 0x1234, 0, n, d_a.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(cid, 0x1234, 0, n, d_a.ptr, NULL_STREAM), "gen")
     x = d_a.to_host().reshape(n, 8)
     assert (x[:64] == po.gen_scalars(fid, 0x1234, 64)).all() and (x[-64:] == po.gen_scalars(fid, 0x1234, 64, first=n - 64)).all()
     flag = C.c_uint(9)
     cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
-    ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
+    ffi.check(fwd_fn(cfg), "ntt")
     assert flag.value == 1  # three passes (fft.cu:193-211)
     fwd, other = (d_b, d_a) if flag.value else (d_a, d_b)
     ks = [0, 1, n // 2, n - 1] + [int(v) for v in rng.integers(0, n, 8)]
@@ -498,7 +501,7 @@ def test_ntt_2_24_values_and_full_roundtrip(gm):
         got = fwd.to_host(nbytes=32, offset=k * 32)
         assert (got == po.ntt_eval_at(fid, x, om, log_n, k)).all(), k
     cfg2 = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, fwd.ptr, other.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
-    ffi.check(lib.panda_ntt_execute_bn254_inverse(cfg2), "intt")
+    ffi.check(inv_fn(cfg2), "intt")
     res = other if flag.value else fwd
     back = res.to_host().reshape(n, 8)
     assert np.array_equal(back, x)
@@ -509,7 +512,7 @@ def test_ntt_2_24_values_and_full_roundtrip(gm):
     ffi.check(lib.panda_memset(d_a.ptr, 0, n * 32), "memset")
     one = pyref.int_to_limbs(c.Rr % c.r, 8)
     ffi.check(lib.panda_memcpy(C.c_void_p(d_a.ptr.value + j * 32), C.c_void_p(one.ctypes.data), 32), "memcpy")
-    ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
+    ffi.check(fwd_fn(cfg), "ntt")
     fwd = d_b if flag.value else d_a
     for k in [0, 1, n - 1] + [int(v) for v in rng.integers(0, n, 61)]:
         want = pyref.int_to_limbs(pow(w, (j * k) % n, c.r) * c.Rr % c.r, 8)
@@ -825,6 +828,136 @@ def test_c_abi_multi_gpu_ntt_batch(gm, ranks, transport, log_n, count):
                 d.free()
 
 
+class _OnDevice:
+    """allocations, generators and copies of one rank run with that rank's device current"""
+
+    def __init__(self, dev):
+        self.dev, self.prev = dev, C.c_int(0)
+
+    def __enter__(self):
+        lib = ffi.load()
+        ffi.check(lib.panda_get_device(C.byref(self.prev)), "get_device")
+        ffi.check(lib.panda_set_device(self.dev), "set_device")
+
+    def __exit__(self, *exc):
+        ffi.load().panda_set_device(self.prev.value)
+
+
+def _box_devices():
+    """every device of the box, up to eight, rounded down to a power of two (the slab decomposition wants one)"""
+    n = C.c_int(0)
+    ffi.check(ffi.load().panda_get_device_number(C.byref(n)), "device_number")
+    g = max(1, min(n.value, 8))
+    return list(range(1 << (g.bit_length() - 1)))
+
+
+def _sharded_over(devs, transport, what):
+    """One sharded operation through the single-process C entry points with rank r's buffers ON devs[r], checked as the one-device tests
+    check it: MSM by linearity over every rank's scalars, NTT against the oracle's plain transform and back through the inverse."""
+    lib = ffi.load()
+    G = len(devs)
+    g = G.bit_length() - 1
+    bufs = []
+
+    def dbuf(r, nbytes=None, host=None):
+        with _OnDevice(devs[r]):
+            b = DeviceBuffer.from_host(host) if host is not None else DeviceBuffer(nbytes)
+        bufs.append((devs[r], b))
+        return b
+
+    def fetch(r, b, shape):
+        with _OnDevice(devs[r]):
+            return b.to_host().reshape(shape)
+
+    mg = multi_gpu.MultiGpu(devs, transport)
+    pinned = []
+    try:
+        if what in ("msm", "msm_from_host"):
+            k = 15
+            per = (1 << k) >> g
+            seed_b, seed_s = 0xB0C5 + G, 0xB0C6 + G
+            db, ds, dr = [dbuf(r, per * 64) for r in range(G)], [dbuf(r, per * 32) for r in range(G)], [dbuf(r, 96) for r in range(G)]
+            for r in range(G):
+                with _OnDevice(devs[r]):
+                    ffi.check(lib.panda_gen_bases(0, seed_b, r * per, per, db[r].ptr, NULL_STREAM), "gen")
+                    ffi.check(lib.panda_gen_scalars(0, seed_s, r * per, per, ds[r].ptr, NULL_STREAM), "gen")
+                    if what == "msm_from_host":
+                        ffi.check(lib.panda_msm_precompute_bases(0, db[r].ptr, k - g, 0, NULL_STREAM), "precompute")
+            scalars = np.concatenate([fetch(r, ds[r], (per, 8)) for r in range(G)])
+            want = po.expected_from_linearity(0, seed_b, scalars)
+            cfgs = [ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), db[r].ptr, ds[r].ptr, dr[r].ptr, k - g, pgm.JACOBIAN) for r in range(G)]
+            if what == "msm":
+                for _ in range(2):
+                    assert (affine_of(0, mg.msm(cfgs)) == want).all()
+                r = G - 1  # every rank's own buffer holds the partial of its own range
+                assert (po.to_affine(0, fetch(r, dr[r], (24,))) == po.expected_from_linearity(0, seed_b, scalars[r * per:], first=r * per)).all()
+            else:
+                hosts = []
+                for r in range(G):
+                    hp = C.c_void_p()
+                    ffi.check(lib.panda_malloc_host(C.byref(hp), per * 32), "malloc_host")
+                    pinned.append(hp)
+                    C.memmove(hp, scalars[r * per:(r + 1) * per].ctypes.data, per * 32)
+                    with _OnDevice(devs[r]):
+                        ffi.check(lib.panda_memset(ds[r].ptr, 0, per * 32), "memset")  # the device copies must come from the host
+                    hosts.append(hp.value)
+                for ranges in (1, 3):
+                    assert (affine_of(0, mg.msm_from_host(cfgs, hosts, ranges)) == want).all()
+                for r in range(G):
+                    with _OnDevice(devs[r]):
+                        lib.panda_msm_unregister_bases(db[r].ptr)
+        else:
+            field = 1 if what == "ntt_bls12_377" else 0
+            fid = po.FR_OF[field]
+            log_n = 13 + g
+            n, m = 1 << log_n, (1 << log_n) >> g
+            om = po.root_of_unity(fid, log_n)
+            count = 3 if what == "ntt_batch" else 1
+            xs = [po.gen_scalars(fid, 0xB0C7 + 16 * t + G, n) for t in range(count)]
+            slabs = [[dbuf(r, host=multi_gpu.slab_of(xs[t], G, r)) for r in range(G)] for t in range(count)]
+            scr = [[dbuf(r, m * 32) for r in range(G)] for t in range(count)]
+            ptr = lambda rows: [[b.ptr.value for b in row] for row in rows]
+            if what == "ntt_batch":
+                flags = mg.ntt_batch(ptr(slabs), ptr(scr), om, log_n)
+            else:
+                flags = [mg.ntt(ptr(slabs)[0], ptr(scr)[0], om, log_n, field=field)]
+            outs = [[(scr[t][r] if flags[t][r] else slabs[t][r], slabs[t][r] if flags[t][r] else scr[t][r]) for r in range(G)] for t in range(count)]
+            for t in range(count):
+                got = multi_gpu.natural_from_slab_outputs([fetch(r, outs[t][r][0], (m, 8)) for r in range(G)])
+                assert (got == po.ntt(fid, xs[t], om, log_n)).all(), t
+            src, oth = [[o[0].ptr.value for o in row] for row in outs], [[o[1].ptr.value for o in row] for row in outs]
+            if what == "ntt_batch":
+                back = mg.ntt_batch(src, oth, om, log_n, inverse=True)
+            else:
+                back = [mg.ntt(src[0], oth[0], om, log_n, inverse=True, field=field)]
+            for t in range(count):
+                for r in range(G):
+                    res = outs[t][r][1] if back[t][r] else outs[t][r][0]
+                    assert (fetch(r, res, (m, 8)) == multi_gpu.slab_of(xs[t], G, r)).all(), (t, r)
+    finally:
+        mg.close()
+        for hp in pinned:
+            lib.panda_free_host(hp)
+        for dev, b in bufs:
+            with _OnDevice(dev):
+                b.free()
+
+
+@pytest.mark.parametrize("what", ["msm", "msm_from_host", "ntt", "ntt_batch", "ntt_bls12_377"])
+@pytest.mark.parametrize("where", ["every_device_rccl", "two_loopback_ranks"])
+def test_c_abi_multi_gpu_widens_with_the_box(gm, where, what):
+    """The sharded entry points with one rank per DEVICE of the box over RCCL (ncclCommInitAll over several devices, the in-place
+    ncclAllGather, the grouped ncclSend / ncclRecv all-to-all, the two-stream batch schedule): skipped on a one-GPU box, a parity result
+    on the first box that has more.  The same body runs with two loopback ranks on device 0, so that it is itself tested everywhere."""
+    if where == "every_device_rccl":
+        devs = _box_devices()
+        if len(devs) < 2:
+            pytest.skip("one GPU on this box: RCCL with more than one rank cannot run here")
+        _sharded_over(devs, ffi.MULTI_RCCL, what)
+    else:
+        _sharded_over([0, 0], ffi.MULTI_LOOPBACK, what)
+
+
 def test_c_abi_multi_gpu_handles_from_two_threads(gm):
     """Two panda_multi_gpu handles alive at once (two sets of worker threads), each driven from its own host thread while the other is
     busy, created and destroyed three times over: every call returns the MSM of its own inputs."""
@@ -968,17 +1101,45 @@ def test_msm_tiny_sizes(gm, k):
         assert (affine_of(cid, out) == po.to_affine(cid, po.msm_naive(cid, bases, scalars))).all()
 
 
-@pytest.mark.parametrize("log_n", [3, 8, 11, 17])
+@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 10, 11, 12, 16, 17, 18, 19, 20])
 def test_ntt_bls12_377_fr(gm, log_n):
-    """The NTT kernels instantiated for the BLS12-377 scalar field (additive entry points)."""
+    """The NTT kernels instantiated for the BLS12-377 scalar field (bls12_377/paramter.cuh:130-181; protocol fft.cu:171-216): every kind of
+    plan -- the LDS kernel below 2^11, radix-256 passes with short and long last passes, the radix-512 plans of 2^17 / 2^18, three passes
+    with two-factor inter-pass tables at 2^19 / 2^20 -- against the oracle, forward and inverse."""
     fid = po.F_BLS377_FR
     om = po.root_of_unity(fid, log_n)
     x = po.gen_scalars(fid, 4000 + log_n, 1 << log_n)
     buf = x.copy()
-    pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n)
+    flag = pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n)
+    assert flag == ntt_passes(log_n) % 2
     assert (buf == po.ntt(fid, x, om, log_n)).all()
     pgm.panda_ntt_bls12_377_gpu_v1(gm, buf, om, log_n, inverse=True)
     assert (buf == x).all()
+
+
+@pytest.mark.parametrize("log_n", [0, 3, 9, 12, 17, 18, 20])
+def test_ntt_bls12_377_bit_reversed_orderings_and_coset(gm, log_n):
+    """panda_ntt_execute_bls12_377_{bitrev_out,inverse_bitrev_in,coset,coset_inverse}: the BN254 variants' semantics over BLS12-377 Fr."""
+    fid = po.F_BLS377_FR
+    c = pyref.CURVES[1]
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 4300 + log_n, n)
+    want = po.ntt(fid, x, om, log_n)
+    perm = np.array([int(format(k, f"0{log_n}b")[::-1], 2) if log_n else 0 for k in range(n)])
+    buf = x.copy()
+    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n)
+    assert (buf[perm] == want).all()  # buf[bitrev(k)] = y[k]
+    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n, inverse=True)
+    assert (buf == x).all()
+    if log_n <= 12:  # coset: y = NTT(x[j] g^j), g^j by Python integers
+        g = pyref.int_to_limbs(7 * c.Rr % c.r, 8)
+        pw = np.stack([pyref.int_to_limbs(pow(7, j, c.r) * c.Rr % c.r, 8) for j in range(n)])
+        buf = x.copy()
+        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n)
+        assert (buf == po.ntt(fid, po.f_vec(fid, po.OP_MUL, x, pw), om, log_n)).all()
+        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n, inverse=True)
+        assert (buf == x).all()
 
 
 def test_msm_and_ntt_from_two_host_threads():
