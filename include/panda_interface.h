@@ -205,6 +205,9 @@ panda_error panda_msm_set_chunk_entries(unsigned entries);
  * after the other, 0xffffffff = built-in policy (default: off -- measured slower on MI355X for BN254, profiles/r05_overlap_sort_accumulate.txt);
  * workgroups_per_cu: 0 = built-in (6 for BN254, three waves per SIMD), at most 64.  Same group element. */
 panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu);
+/* Experiments on the bucket-accumulation kernel of the 9-limb base fields (BN254): 0 = the built-in choice, 1 = five waves per SIMD with
+ * the next entry's table row staged in LDS (global_load_lds) instead of registers, 2 = four waves per SIMD with the staged row. */
+panda_error panda_msm_set_accumulate_variant(unsigned variant);
 /* deprecated no-op kept so that code linked against the round-3 interface still loads (the bucket reduction has no groups any more) */
 panda_error panda_msm_set_reduce_group(unsigned log_group);
 /* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = none (default),

@@ -211,6 +211,7 @@ std::atomic<unsigned> g_paranoid{0};
 constexpr unsigned kOverlapAuto = 0xffffffffu;
 std::atomic<unsigned> g_overlap_front{kOverlapAuto};
 std::atomic<unsigned> g_overlap_wgs{0};
+std::atomic<unsigned> g_acc_variant{0};
 
 // With tables, the accumulation of the first `front / 128` of the bucket space can run beside the sort of the rest (msm_impl.h,
 // "want_split").  Measured in round 5 and NOT the policy (profiles/r05_overlap_sort_accumulate.txt): k_accumulate<Bn254Fq> needs its
@@ -275,7 +276,8 @@ unsigned pick_tabled_window_bits(unsigned fr, unsigned log_n)
 hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, const panda::MsmRegistration *r, bool *stale, const panda::MsmPipeline *pipe)
 {
     const panda::MsmTuning tuning{pick_window_bits(panda::msm_scalar_field_of(curve), cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
-                                  g_phase_timing.load(std::memory_order_relaxed), pick_overlap_front(cfg.log_scalars_count), g_overlap_wgs.load(std::memory_order_relaxed)};
+                                  g_phase_timing.load(std::memory_order_relaxed), pick_overlap_front(cfg.log_scalars_count), g_overlap_wgs.load(std::memory_order_relaxed),
+                                  g_acc_variant.load(std::memory_order_relaxed)};
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
     case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
@@ -532,6 +534,13 @@ panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per
     if ((front_of_128 >= 128 && front_of_128 != kOverlapAuto) || workgroups_per_cu > 64) return panda_error_invalid_value;
     g_overlap_front.store(front_of_128, std::memory_order_relaxed);
     g_overlap_wgs.store(workgroups_per_cu, std::memory_order_relaxed);
+    return panda_success;
+}
+
+panda_error panda_msm_set_accumulate_variant(unsigned variant)
+{
+    if (variant > 2) return panda_error_invalid_value;
+    g_acc_variant.store(variant, std::memory_order_relaxed);
     return panda_success;
 }
 

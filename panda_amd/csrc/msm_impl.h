@@ -58,6 +58,7 @@ struct MsmTuning {
     unsigned timing;       // 0: no device timers at all; 1: the call's total + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
     unsigned overlap_front; // with tables: size of the front part of the bucket space, in 1/128, whose accumulation runs beside the sort of the rest (0 = no overlap)
     unsigned overlap_wgs;   // workgroups per CU of that accumulation (6 = three waves per SIMD); 0 = the curve's default
+    unsigned acc_variant;   // experiments on k_accumulate (9-limb fields): 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -340,11 +341,39 @@ __device__ __forceinline__ void unpack_base(Fe<F> &x, Fe<F> &y, bool &inf, const
 struct AccPart {
     const u32 *pos;
     unsigned lo, hi, last, hi_bucket;
+    u32 *queue; // PERSIST launches: a counter, zero at launch, from which every wave draws its next 64 chunks
 };
 
+// LDSROW: the row of the NEXT entry travels from HBM straight into LDS (global_load_lds_dwordx4: lane l's 16-byte pieces land at
+// piece * 1 KB + 16 l of the wave's region) instead of sitting packed in 2 L registers for the whole addition it is fetched under; it is
+// read back when its turn comes.  That frees 16 (24) registers through the long part of the loop -- what a fifth wave per SIMD needs.
 template <class F>
+__device__ __forceinline__ void fetch_base_lds(uint4 *lds_wave, const u32 *bases, u32 entry)
+{
+    const u32 *src = bases + (u64)(entry & 0x7fffffffu) * 2 * F::L;
+#pragma unroll
+    for (int j = 0; j < 2 * F::L / 4; j++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * j), (__attribute__((address_space(3))) void *)(lds_wave + j * 64), 16, 0, 0);
+}
+template <class F>
+__device__ __forceinline__ void read_base_lds(PackedBase<F> &b, const uint4 *lds_wave, unsigned lane)
+{
+    // the row was sent to LDS one iteration ago; the compiler's own wait in front of an aliasing LDS read is not placed on every path of
+    // a loop-carried transfer (the first build read stale rows), so it is spelled out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2 * F::L / 4; j++) {
+        const uint4 v = lds_wave[j * 64 + lane];
+        b.w[4 * j] = v.x;
+        b.w[4 * j + 1] = v.y;
+        b.w[4 * j + 2] = v.z;
+        b.w[4 * j + 3] = v.w;
+    }
+}
+
+template <class F, bool LDSROW>
 __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, const u32 *__restrict__ sw, const u32 *__restrict__ ow, u32 *__restrict__ bw, u32 *__restrict__ pw,
-                                                 unsigned search_hi, u32 start, u32 end)
+                                                 unsigned search_hi, u32 start, u32 end, uint4 *lds_wave, unsigned lane)
 {
     constexpr int PW = 4 * F::N;
     u32 b = owner_bucket(ow, search_hi, start);
@@ -368,11 +397,15 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
     if (quads) quad = *reinterpret_cast<const uint4 *>(sw + start); // at most 12 bytes past the list's end, inside the arena
     u32 cur_entry = quads ? quad.x : sw[start];
     u32 ahead_entry = quads ? quad.y : (start + 1 < end ? sw[start + 1] : 0u);
-    fetch_base<F>(next_base, bases, cur_entry);
+    if constexpr (LDSROW)
+        fetch_base_lds<F>(lds_wave, bases, cur_entry);
+    else
+        fetch_base<F>(next_base, bases, cur_entry);
     for (u32 pos = start; pos < end; pos++) {
         Fe<F> cx, cy;
         bool cinf;
         const u32 entry = cur_entry;
+        if constexpr (LDSROW) read_base_lds<F>(next_base, lds_wave, lane);
         unpack_base<F, ACC_RAW_Y && RawOperandOk<F>::value>(cx, cy, cinf, next_base, entry);
         const bool boundary = pos >= next;
         if (boundary) { // the run of bucket b ends here; this entry opens the next run, so it simply becomes the accumulator
@@ -392,7 +425,10 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
         }
         if (pos + 1 < end) {
             cur_entry = ahead_entry;
-            fetch_base<F>(next_base, bases, cur_entry);
+            if constexpr (LDSROW)
+                fetch_base_lds<F>(lds_wave, bases, cur_entry);
+            else
+                fetch_base<F>(next_base, bases, cur_entry);
             if (pos + 2 < end) {
                 if (quads) {
                     const u32 idx = pos + 2 - start;
@@ -428,12 +464,13 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
     store_xyzz<F>(dst, acc);
 }
 
-// PERSIST: the grid is a fixed number of workgroups (a few per CU) whose threads walk the chunks t, t + threads, ... -- the launch
-// that runs BESIDE the sort of the rest of the list: three of its waves per SIMD keep the vector pipe as good as full and leave a
-// quarter of the register file and all of the LDS to the sort's workgroups on the other stream (a grid of one thread per chunk fills
-// every wave slot for as long as it has chunks left, and the other stream's workgroups wait).
-template <class F, bool PERSIST>
-__global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
+// PERSIST: the grid is a fixed number of workgroups (a few per CU), all resident at once, whose waves draw their chunks -- 64
+// consecutive ones at a time -- from a counter (part.queue).  This is the launch that runs BESIDE the sort of the rest of the list: a
+// grid of one thread per chunk keeps the command processor placing workgroups for as long as it has chunks left, and the kernels of
+// the second stream are not even started until it is through (profiles/r05_overlap_sort_accumulate.txt, A); a grid that is placed in
+// one go leaves the dispatcher to them.  (Chunks handed out statically, t, t + threads, ..., ran 15 % slower: ibid., B.)
+template <class F, bool PERSIST, int WAVES = (F::N <= 9 ? 4 : 2), bool LDSROW = false>
+__global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
                                                     unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale, AccPart part)
 {
@@ -451,8 +488,30 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
     const bool takes_short_chunk = part.pos ? part.last != 0 : true;
     const u32 *sw = sorted + (u64)w * stride;
     u32 *bw = bucket_acc + (u64)w * NB * PW;
+    __shared__ uint4 s_rows[LDSROW ? 2 * (2 * F::L / 4) * 64 : 1]; // a wave's region: 2 L / 4 pieces of 1 KB
+    uint4 *lds_wave = s_rows + (threadIdx.x >> 6) * (LDSROW ? (2 * F::L / 4) * 64 : 0);
+    const unsigned lane = threadIdx.x & 63u;
+    if constexpr (PERSIST) {
+        const unsigned first = lo_pos / K; // the chunks before it end at or below lo_pos: an earlier launch's
 #pragma unroll 1
-    for (unsigned t = t0; t < chunks; t += gridDim.x * blockDim.x) {
+        for (;;) { // every wave leaves when the counter has passed the part's last chunk
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(part.queue, 64u);
+            base = __builtin_amdgcn_readfirstlane(base) + first;
+            if (base >= chunks || (u64)base * K >= limit) return;
+            const unsigned t = base + lane;
+            const u32 start = t * K;
+            u32 end = start + K;
+            bool mine = t < chunks && start < limit;
+            if (end > limit) {
+                mine = mine && takes_short_chunk;
+                end = limit;
+            }
+            if (mine && end > lo_pos) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
+        }
+    } else {
+        const unsigned t = t0;
+        if (t >= chunks) return;
         const u32 start = t * K;
         if (start >= limit) return;
         u32 end = start + K;
@@ -460,8 +519,7 @@ __global__ void __launch_bounds__(128, (F::N <= 9 ? 4 : 2)) k_accumulate(const u
             if (!takes_short_chunk) return; // ends among entries a later launch owns
             end = limit;
         }
-        if (end > lo_pos) accumulate_chunk<F>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end);
-        if (!PERSIST) return;
+        if (end > lo_pos) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
     }
 }
 
@@ -918,9 +976,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     static thread_local SplitEvents split_events;
     panda::SortSplit split{};
     const bool want_split = tabled && nranges == 1 && tuning.overlap_front != 0 && tuning.overlap_front < 128;
-    // workgroups per CU of the accumulation that runs beside the sort: one wave per SIMD fewer than the kernel's own occupancy for the
-    // 9-limb fields (4 x 128 registers fill the file); the 14-limb fields run two waves of ~176 registers anyway, which already leaves room
-    const unsigned overlap_wgs = tuning.overlap_wgs ? tuning.overlap_wgs : (Fq::N <= 9 ? 6u : 4u);
+    // workgroups per CU of the accumulation that runs beside the sort: the kernel's own occupancy (8 x 2 waves of 104 registers for the
+    // 9-limb fields with the row staged in LDS, 4 x 2 waves of ~176 for the 14-limb fields): both leave the sort's workgroups room
+    const unsigned overlap_wgs = tuning.overlap_wgs ? tuning.overlap_wgs : (Fq::N <= 9 ? 8u : 4u);
     if (want_split) {
         int dev = -1;
         PANDA_TRY(hipGetDevice(&dev));
@@ -1032,15 +1090,37 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             // the front of the list, in a grid small enough to leave room on every CU, while the helper stream sorts the rest; then the rest
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, registration->device);
-            const unsigned persist_wgs = std::min((unsigned)cus * overlap_wgs, (g.chunks + 127) / 128);
-            hipLaunchKernelGGL((k_accumulate<Fq, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K, g.chunks,
-                               d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, 0u, split.cut_cell, 0u, split.cut_bucket});
+            const unsigned all_wgs = (g.chunks + 127) / 128, persist_wgs = std::min((unsigned)cus * overlap_wgs, all_wgs);
+            u32 *d_queue = d_stale + 16; // a word of the flag block
+            const AccPart front{split.pos, 0u, split.cut_cell, 0u, split.cut_bucket, d_queue};
+            if (persist_wgs == all_wgs)
+                hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K, g.chunks,
+                                   d_lcount, registered ? d_stale : nullptr, front);
+            else {
+                PANDA_TRY(hipMemsetAsync(d_queue, 0, 4, ls));
+                if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
+                    // the kernel with its row staged in LDS, built for 96 registers: 8 workgroups per CU (4 waves per SIMD) leave 128 per SIMD (and 96 KB of LDS) to the sort's
+                    // 1024-thread workgroups of at most 24 registers
+                    hipLaunchKernelGGL((k_accumulate<Fq, true, 5, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
+                                       g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                else
+                    hipLaunchKernelGGL((k_accumulate<Fq, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+            }
             PANDA_TRY(hipStreamWaitEvent(ls, split.rest_done, 0));
             hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
-                               g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB});
+                               g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB, nullptr});
+        } else if (Fq::N <= 9 && !IsExt2<Fq>::value && tuning.acc_variant == 1) {
+            if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // five waves per SIMD, the next row staged in LDS (experiment: panda_msm_set_accumulate_variant)
+                hipLaunchKernelGGL((k_accumulate<Fq, false, 5, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
+                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
+        } else if (Fq::N <= 9 && !IsExt2<Fq>::value && tuning.acc_variant == 2) {
+            if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // four waves per SIMD with the LDS-staged row
+                hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
+                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
         } else
             hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
-                               NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB});
+                               NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
         if (last && wanted(4)) PANDA_TRY(hipEventRecord(ev[4], ls));
         // 256-thread workgroups: at 2^16 buckets that is one per CU, a wave per SIMD (with 128 the dispatcher doubled them up on half
         // the CUs and every addition took 1.6x as long: fix-up 0.225 -> 0.162 ms at 2^20 points)

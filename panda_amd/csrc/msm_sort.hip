@@ -553,6 +553,7 @@ __device__ __forceinline__ bool locate_tile(TileRange &r, unsigned &tile, unsign
 __global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off, const u32 *__restrict__ seg_tile,
                                                u32 *__restrict__ tile_hist, TabledGeom g, SortRange R)
 {
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
     __shared__ u32 h[256];
     const unsigned tid = threadIdx.x;
     unsigned tile;
@@ -577,10 +578,12 @@ __global__ void __launch_bounds__(256) k2_hist(const unsigned char *__restrict__
 }
 
 // one WAVE per (segment, h2) column: exclusive prefix over the segment's tiles (tile_pref), column total to totals[s][h2]
-__global__ void __launch_bounds__(1024) k2_scan_cols(const u32 *__restrict__ tile_hist, u32 *__restrict__ tile_pref, const u32 *__restrict__ seg_tile,
-                                                     u32 *__restrict__ totals, TabledGeom g, SortRange R)
+__global__ void __launch_bounds__(256) k2_scan_cols(const u32 *__restrict__ tile_hist, u32 *__restrict__ tile_pref, const u32 *__restrict__ seg_tile,
+                                                    u32 *__restrict__ totals, TabledGeom g, SortRange R)
 {
-    const unsigned s = R.s_lo + blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 16 + (threadIdx.x >> 6);
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
+    // four waves, four columns (a wave per SIMD: sixteen-wave workgroups of this kernel took 3.9 ms beside the accumulation, 0.03 alone)
+    const unsigned s = R.s_lo + blockIdx.y, lane = threadIdx.x & 63, h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= g.H2) return; // whole wave exits together
     const unsigned t_begin = seg_tile[s], t_end = seg_tile[s + 1];
     u32 run = 0;
@@ -601,6 +604,7 @@ __global__ void __launch_bounds__(1024) k2_scan_cols(const u32 *__restrict__ til
 // one block per segment: sub_off[s][0..H2] = exclusive scan of the column totals (relative to the segment start)
 __global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals, u32 *__restrict__ sub_off, TabledGeom g, SortRange R)
 {
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
     __shared__ u32 tot[256];
     const unsigned s = R.s_lo + blockIdx.x, t = threadIdx.x;
     const u32 mine = t < g.H2 ? totals[(u64)s * g.H2 + t] : 0;
@@ -621,6 +625,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
                                                   const u32 *__restrict__ seg_tile, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
                                                   const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g, SortRange R)
 {
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
     __shared__ u32 lstart[256], lcur[256];
     __shared__ u64 gbase[256];
     __shared__ u32 words[SORT_TILE];
@@ -682,33 +687,41 @@ __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsig
 // cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b.  per_window: cell q = k * Q + (h1 * H2 + h2)
 __device__ __forceinline__ unsigned cells_total(const TabledGeom &g) { return g.per_window ? g.W * g.Q : g.Q; }
 
-__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g, SortRange R)
+// 256 threads per block of 1024 cells (one wave per SIMD: the kernel has to find room beside the bucket accumulation when it runs for the
+// rest of a split sort, see k3_merge_small)
+__global__ void __launch_bounds__(256) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g, SortRange R)
 {
-    __shared__ u32 red[1024];
-    const unsigned blk = R.q_lo / 1024 + blockIdx.x, q = blk * 1024 + threadIdx.x, t = threadIdx.x;
-    u32 total = 0;
-    if (q < R.q_hi) {
-        const unsigned cell = g.per_window ? q % g.Q : q;
-        const unsigned h1 = cell / g.H2, h2 = cell % g.H2;
-        const unsigned k_begin = g.per_window ? q / g.Q : 0u, k_end = g.per_window ? k_begin + 1 : g.W;
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
+    __shared__ u32 red[4];
+    const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x;
+    const unsigned qbits = g.b1 + g.b2; // H2 and Q = H1 H2 are powers of two
+    u32 sum = 0;
+#pragma unroll 1
+    for (unsigned j = 0; j < 4; j++) {
+        const unsigned q = blk * 1024 + j * 256 + t;
+        if (q >= R.q_hi) break;
+        const unsigned cell = g.per_window ? q & ((1u << qbits) - 1) : q;
+        const unsigned h1 = cell >> g.b2, h2 = cell & (g.H2 - 1);
+        const unsigned k_begin = g.per_window ? q >> qbits : 0u, k_end = g.per_window ? k_begin + 1 : g.W;
+        u32 total = 0;
+#pragma unroll 1
         for (unsigned k = k_begin; k < k_end; k++) {
-            const u32 *so = sub_off + (u64)seg_of(g, k, h1) * (g.H2 + 1);
-            total += so[h2 + 1] - so[h2];
+            const unsigned at = seg_of(g, k, h1) * (g.H2 + 1) + h2; // < 2^14 segments x 257
+            total += sub_off[at + 1] - sub_off[at];
         }
         cell_cnt[q] = total;
+        sum += total;
     }
-    red[t] = total;
+    for (unsigned d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((t & 63) == 0) red[t >> 6] = sum;
     __syncthreads();
-    for (unsigned s = 512; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
-    }
-    if (t == 0) blk_sum[blk] = red[0];
+    if (t == 0) blk_sum[blk] = red[0] + red[1] + red[2] + red[3];
 }
 
 // cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block
 __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ cell_off, TabledGeom g, SortRange R)
 {
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
     __shared__ u32 red[1024];
     __shared__ u32 sc[1024];
     const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
@@ -870,6 +883,86 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         const u32 v = p2[rbegin[k] + (p - vstart[k])];
         sw[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
     }
+}
+
+// The same merge (tabled mode only) in at most 24 registers per thread: two passes over the cell's runs -- count, then rank into the LDS
+// image (or, for an oversized cell, straight into the list) -- instead of sixteen words and their ranks held in registers.  A
+// 1024-thread workgroup of it fits the 96 registers per SIMD that the bucket accumulation with its row staged in LDS leaves free, so the
+// rest of the list can be merged BESIDE the accumulation of its front (SortSplit).  Two LDS atomics per entry instead of one.
+__global__ void __launch_bounds__(K3_THREADS) k3_merge_small(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
+                                                    const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
+{
+    __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
+    __shared__ u32 cnt[128], cur[128], scan_carry;
+    __shared__ u32 outbuf[K3_CAP];
+    __shared__ u32 rbegin_lo[64], vstart[65]; // a run's start in p2 as (k << log_n) + rbegin_lo[k]
+    const unsigned tid = threadIdx.x;
+    const unsigned q = R.q_lo + blockIdx.x;
+    const unsigned h1 = q / g.H2, h2 = q % g.H2;
+    const unsigned L = 1u << g.b3;
+    const u32 out_rel = cell_off[q];
+    if (tid < g.W) {
+        const unsigned at = seg_of(g, tid, h1) * (g.H2 + 1) + h2;
+        const u32 so = sub_off[at];
+        rbegin_lo[tid] = part_off[tid * (g.H1 + 1) + h1] + so;
+        vstart[tid + 1] = sub_off[at + 1] - so; // lengths; prefixed below
+    }
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (unsigned k = 0; k < g.W; k++) {
+            const u32 len = vstart[k + 1];
+            vstart[k] = run;
+            run += len;
+        }
+        vstart[g.W] = run;
+    }
+    __syncthreads();
+    const u32 N = vstart[g.W]; // uniform over the block
+    const unsigned shift = g.log_n + 1;
+    if (q + 1 == R.q_hi && q + 1 < g.Q && tid == 0) off[(u64)(q + 1) << g.b3] = out_rel + N; // see k3_merge, closes_part
+    if (N == 0) {
+        if (tid < L) off[((u64)q << g.b3) + tid] = out_rel;
+        if (q == g.Q - 1 && tid == 0) off[NB] = out_rel;
+        return;
+    }
+    // pass 1: count.  A thread's positions grow by K3_THREADS, about one run: the run index only ever steps forward
+    unsigned k = 0;
+#pragma unroll 1
+    for (u32 p = tid; p < N; p += K3_THREADS) {
+        while (p >= vstart[k + 1]) k++;
+        atomicAdd(&cnt[p2[((u64)k << g.log_n) + rbegin_lo[k] + (p - vstart[k])] >> shift], 1u);
+    }
+    __syncthreads();
+    const u32 mine = tid < 128 ? cnt[tid] : 0;
+    scan128_inclusive(cnt, &scan_carry);
+    if (tid < L) {
+        const u32 start = cnt[tid] - mine; // local
+        cur[tid] = start;
+        off[((u64)q << g.b3) + tid] = out_rel + start;
+    }
+    if (q == g.Q - 1 && tid == 0) off[NB] = out_rel + N;
+    __syncthreads();
+    // pass 2: the same words again (L2), each to the next free slot of its bucket
+    const bool in_lds = N <= K3_CAP;
+    const u32 id_mask = (1u << g.log_n) - 1;
+    k = 0;
+#pragma unroll 1
+    for (u32 p = tid; p < N; p += K3_THREADS) {
+        while (p >= vstart[k + 1]) k++;
+        const u32 v = p2[((u64)k << g.log_n) + rbegin_lo[k] + (p - vstart[k])];
+        const u32 word = ((v & id_mask) + g.row0 + (k << g.row_shift)) | (((v >> g.log_n) & 1u) << 31);
+        const u32 slot = atomicAdd(&cur[v >> shift], 1u);
+        if (in_lds)
+            outbuf[slot] = word;
+        else
+            sorted[out_rel + slot] = word;
+    }
+    if (!in_lds) return;
+    __syncthreads();
+#pragma unroll 1
+    for (u32 p = tid; p < N; p += K3_THREADS) sorted[out_rel + p] = outbuf[p];
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -1142,16 +1235,19 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     // workgroups beyond the range's last tile leave after two loads.
     auto level2 = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k2_hist, dim3(g.max_tiles2), dim3(256), 0, s, d_p1_hi, d_poff, d_segtile, d_thist2, g, R);
-        hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 15) / 16, R.s_hi - R.s_lo), dim3(1024), 0, s, d_thist2, d_tpref2, d_segtile, d_tot2, g, R);
+        hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 3) / 4, R.s_hi - R.s_lo), dim3(256), 0, s, d_thist2, d_tpref2, d_segtile, d_tot2, g, R);
         hipLaunchKernelGGL(k2_offsets, dim3(R.s_hi - R.s_lo), dim3(256), 0, s, d_tot2, d_suboff, g, R);
         hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
     };
     auto level3_counts = [&](hipStream_t s, const SortRange &R) {
-        hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
+        hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(256), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
     };
     auto level3_merge = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
-        hipLaunchKernelGGL(k3_merge, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
+        if (s == stream)
+            hipLaunchKernelGGL(k3_merge, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
+        else // on the helper stream, beside the accumulation of the front: the variant that fits next to it
+            hipLaunchKernelGGL(k3_merge_small, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
     };
     // the cut between the front and the rest: a level-1 partition boundary whose first cell starts a block of 1024 cells
     unsigned cut_h1 = 0;

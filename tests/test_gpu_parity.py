@@ -1495,6 +1495,37 @@ def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, w
         d.free()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("k,wbits,kind", [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (13, 14, "all_equal"), (13, 14, "half_zero"), (13, 14, "small"), (13, 0, "plain")])
+def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
+    """panda_msm_set_accumulate_variant: k_accumulate with the next entry's row staged in LDS (global_load_lds) at five / four waves per
+    SIMD -- the same group element as the oracle says, with tables and on the plain path, uniform and skewed scalars, identity rows"""
+    lib = ffi.load()
+    n = 1 << k
+    db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
+    seed_b = 0x1D5 + k
+    bases = po.gen_bases(0, seed_b, n)
+    bases[5::97, :8] = 0  # identity rows (x == 0)
+    ffi.check(lib.panda_memcpy(db.ptr, C.c_void_p(bases.ctypes.data), n * 64), "memcpy")
+    scalars = po.gen_scalars(po.F_BN254_FR, 0x1D6 + k, n) if kind in ("uniform", "plain") else _edge_scalars(kind, n)
+    ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(np.ascontiguousarray(scalars).ctypes.data), n * 32), "memcpy")
+    if kind != "plain":
+        ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, k, wbits, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    try:
+        ffi.check(lib.panda_msm_set_accumulate_variant(variant), "variant")
+        for _ in range(2):
+            ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        got = po.to_affine(0, dr.to_host())
+    finally:
+        lib.panda_msm_set_accumulate_variant(0)
+        lib.panda_msm_unregister_bases(db.ptr)
+    assert (got == po.msm_affine(0, bases, scalars, window_bits=11)).all()
+    assert lib.panda_msm_set_accumulate_variant(3) != 0
+    for d in (db, ds, dr):
+        d.free()
+
+
 @pytest.mark.parametrize("kind", ["all_equal", "half_zero", "three_values", "all_equal_from_host_5_ranges"])
 def test_msm_skewed_scalars_full_size_2_22(gm, kind):
     """Skew at a size where it bites: 2^22 points with precomputed tables.  Equal scalars put 2^22 entries into ONE bucket per window

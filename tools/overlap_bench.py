@@ -25,6 +25,7 @@ def main():
     lib = ffi.load()
     timing = int(os.environ.get("PANDA_TIMING", "0"))
     lib.panda_msm_set_phase_timing(timing)
+    lib.panda_msm_set_accumulate_variant(int(os.environ.get("PANDA_ACC_VARIANT", "0")))
     fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381, lib.panda_msm_execute_bn254_g2)[curve]
     gm = pgm.PandaGpuManager(0)
     names = [lib.panda_msm_phase_name(i).decode() for i in range(8)]
