@@ -492,6 +492,23 @@ PandaGpuError PandaMultiGpuManager::ntt_bn254_batch(const std::vector<uint8_t *>
     for (uint8_t *p : polys)
         if (!p) return PandaGpuError::NttExecErr;
     const size_t m = n / G, chunk = m / G;
+    // A batch is staged in windows: every transform of a window holds a slab and a scratch buffer of m elements on every device, and
+    // the pipeline behind panda_ntt_execute_bn254_multi_batch is only two or three transforms deep, so a long batch gains nothing from
+    // being resident all at once and would run out of memory where the same transforms one by one succeed.
+    size_t window = 8;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (set_device((size_t)devices_[0]) == PandaGpuError::Ok && panda_mem_get_info(&free_b, &total_b) == 0)
+            window = std::max<size_t>(1, std::min<size_t>(window, free_b / 2 / (2 * m * FIELD_ELEMENT_LEN)));
+    }
+    if (count > window) {
+        for (size_t first = 0; first < count; first += window) {
+            const std::vector<uint8_t *> part(polys.begin() + first, polys.begin() + std::min(count, first + window));
+            const PandaGpuError e = ntt_bn254_batch(part, len, omega, log_n);
+            if (e != PandaGpuError::Ok) return e;
+        }
+        return PandaGpuError::Ok;
+    }
     struct Staged {
         std::vector<void *> ptrs;
         std::vector<int> dev;

@@ -230,9 +230,12 @@ const char *const kPhaseNames[PANDA_MSM_PHASES] = {"convert_bases+digits", "sort
 // A bucket costs about as much as five mixed additions by the time it has been through the fix-up, the row / column sums and the
 // finishing kernel (fitted to 2^20 ... 2^24 points with and without tables: profiles/r04_window_sweeps.txt).
 constexpr double kBucketCost = 5.0;
+// The same quantity on the plain path, fitted separately (ibid.): 4.5.  There every window has a bucket space of its own, a quarter to a
+// sixteenth the size of the tables' shared one, so the row / column sums are shorter lines and the fix-up has fewer pieces per bucket.
+constexpr double kBucketCostPlain = 4.5;
 
 // window width policy of the plain path (replaces get_window_bits_count, msm_cuda.cuh:21-45): every window has its own 2^(c-1) buckets
-// (signed digits), so minimise  W(c) * (n * s(c) + 4.5 * 2^(c-1))  over the widths the sort supports, s = 1.04 for the windows wider
+// (signed digits), so minimise  W(c) * (n * s(c) + kBucketCostPlain * 2^(c-1))  over the widths the sort supports, s = 1.04 for the windows wider
 // than 16 bits (their three-level sort moves every entry once more): 16 bits up to 2^22 points, 17 at 2^23, 20 from 2^24 on
 // (measured: 2^24 21.4 -> 19.7 ms, 2^23 11.09 -> 10.8; rounds 1-3 stopped at 16 bits: two-byte digit codes and a two-level sort)
 unsigned pick_window_bits(unsigned fr, unsigned log_n)
@@ -246,7 +249,7 @@ unsigned pick_window_bits(unsigned fr, unsigned log_n)
     for (unsigned c = 4; c <= 20; c++) {
         const panda::WindowPlan plan = panda::make_safe_window_plan(fr, c);
         if (plan.width[0] != c || !panda::msm_sort_plain_supported(log_n, plan)) continue;
-        const double cost = (double)plan.W * ((double)((u64)1 << log_n) * (c > 16 ? 1.04 : 1.0) + 4.5 * (double)(1u << (c - 1)));
+        const double cost = (double)plan.W * ((double)((u64)1 << log_n) * (c > 16 ? 1.04 : 1.0) + kBucketCostPlain * (double)(1u << (c - 1)));
         if (!best || cost < best_cost) {
             best = c;
             best_cost = cost;

@@ -887,6 +887,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         // (a 2^21-point range at K = 128 kept three waves per SIMD busy: 2.4 ms instead of 1.8); 64 ... 256 measure the same at 2^24
         const u64 per_k = ((u64)lists * g.stride) >> 20;
         g.K = per_k >= 128 ? 128 : (per_k >= 64 ? 64 : (per_k >= 32 ? 32 : 16));
+        // below 2^22 points the threads are fewer than four rounds of the chip and the best chunk is a matter of how the last round fills:
+        // interleaved sweeps (tools/chunk_sweep.py, profiles/r05_chunk_sweep.txt) put 24 in front at 2^19 (-3.4 %) and 32 at 2^20 / 2^21 (-1 %)
+        if (Fq::N <= 9 && per_k < 32) g.K = per_k >= 12 ? 32 : (per_k >= 6 ? 24 : 16);
         if (tuning.chunk) g.K = std::min(std::max((tuning.chunk + 3u) & ~3u, 4u), 1024u); // multiples of four: chunks start on 16 bytes
         g.chunks = (unsigned)((g.stride + g.K - 1) / g.K);
         g.long_cap = g.chunks / LONG_SPAN + 2;

@@ -687,19 +687,17 @@ __device__ __forceinline__ void cell_run(u64 &begin, u32 &len, unsigned k, unsig
 // cell_cnt[q] = entries of cell q; blk_sum[b] = sum over the 1024 cells of block b.  per_window: cell q = k * Q + (h1 * H2 + h2)
 __device__ __forceinline__ unsigned cells_total(const TabledGeom &g) { return g.per_window ? g.W * g.Q : g.Q; }
 
-// 256 threads per block of 1024 cells (one wave per SIMD: the kernel has to find room beside the bucket accumulation when it runs for the
-// rest of a split sort, see k3_merge_small)
-__global__ void __launch_bounds__(256) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g, SortRange R)
+// A block of 1024 cells per workgroup of 1024 threads -- or of 256 (one wave per SIMD) when the kernel runs for the rest of a split sort
+// and has to find room beside the bucket accumulation (see k3_merge_small)
+__global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ sub_off, u32 *__restrict__ cell_cnt, u32 *__restrict__ blk_sum, TabledGeom g, SortRange R)
 {
     __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
-    __shared__ u32 red[4];
+    __shared__ u32 red[16];
     const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x;
     const unsigned qbits = g.b1 + g.b2; // H2 and Q = H1 H2 are powers of two
     u32 sum = 0;
 #pragma unroll 1
-    for (unsigned j = 0; j < 4; j++) {
-        const unsigned q = blk * 1024 + j * 256 + t;
-        if (q >= R.q_hi) break;
+    for (unsigned q = blk * 1024 + t; q < blk * 1024 + 1024 && q < R.q_hi; q += blockDim.x) {
         const unsigned cell = g.per_window ? q & ((1u << qbits) - 1) : q;
         const unsigned h1 = cell >> g.b2, h2 = cell & (g.H2 - 1);
         const unsigned k_begin = g.per_window ? q >> qbits : 0u, k_end = g.per_window ? k_begin + 1 : g.W;
@@ -715,7 +713,11 @@ __global__ void __launch_bounds__(256) k3_cell_counts(const u32 *__restrict__ su
     for (unsigned d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
     if ((t & 63) == 0) red[t >> 6] = sum;
     __syncthreads();
-    if (t == 0) blk_sum[blk] = red[0] + red[1] + red[2] + red[3];
+    if (t == 0) {
+        u32 v = 0;
+        for (unsigned i = 0; i < blockDim.x / 64; i++) v += red[i];
+        blk_sum[blk] = v;
+    }
 }
 
 // cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block
@@ -1240,7 +1242,7 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
         hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
     };
     auto level3_counts = [&](hipStream_t s, const SortRange &R) {
-        hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(256), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
+        hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
     };
     auto level3_merge = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);

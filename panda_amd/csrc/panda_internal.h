@@ -73,9 +73,12 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // kernel read past it and take the process down; with this the entry point answers panda_error_invalid_value.  Pointers from other
 // allocators pass unchecked: the runtime's own description of them (hipMemGetAddressRange, which round 3 used) is one mapped CHUNK for
 // virtual-memory mappings such as torch's expandable segments, so a valid buffer spanning several chunks would be refused -- the check
-// only ever refuses what is provably too short.  No runtime call: a lookup in a small ordered map.
+// only ever refuses what is provably too short.  No runtime call: a lookup in a small ordered map.  Extents leave the map with
+// panda_free / panda_free_async and, for pool memory, with panda_mem_pool_destroy; memory released behind the library's back (hipFree, a
+// pool trim) keeps a stale extent until its address is tracked again -- release what panda_malloc* gave through panda_free*.
 bool extent_too_short(const void *ptr, size_t bytes);
-void track_allocation(const void *ptr, size_t bytes);
+void track_allocation(const void *ptr, size_t bytes, const void *pool = nullptr);
+void untrack_pool(const void *pool); // panda_mem_pool_destroy: the pool's extents go with it
 void untrack_allocation(const void *ptr);
 
 } // namespace panda

@@ -14,14 +14,27 @@ namespace panda {
 namespace {
 std::mutex g_alloc_mutex;
 // deliberately never destroyed (allocations may be freed from static destructors of the host program)
-std::map<uintptr_t, size_t> &g_allocs = *new std::map<uintptr_t, size_t>();
+struct Extent {
+    size_t bytes;
+    const void *pool; // the stream-ordered pool the memory came from, nullptr for panda_malloc
+};
+std::map<uintptr_t, Extent> &g_allocs = *new std::map<uintptr_t, Extent>();
 } // namespace
 
-void track_allocation(const void *ptr, size_t bytes)
+void track_allocation(const void *ptr, size_t bytes, const void *pool)
 {
     if (!ptr) return;
     std::lock_guard<std::mutex> lock(g_alloc_mutex);
-    g_allocs[(uintptr_t)ptr] = bytes;
+    g_allocs[(uintptr_t)ptr] = Extent{bytes, pool};
+}
+
+// a destroyed pool takes its memory with it: extents that were never handed back through panda_free_async must not outlive it (another
+// allocator may reuse the range for a LARGER buffer, which a stale, smaller extent would refuse)
+void untrack_pool(const void *pool)
+{
+    if (!pool) return;
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    for (auto it = g_allocs.begin(); it != g_allocs.end();) it = it->second.pool == pool ? g_allocs.erase(it) : std::next(it);
 }
 
 void untrack_allocation(const void *ptr)
@@ -40,7 +53,7 @@ bool extent_too_short(const void *ptr, size_t bytes)
     if (it == g_allocs.begin()) return false;
     --it;
     const uintptr_t base = it->first;
-    const size_t size = it->second;
+    const size_t size = it->second.bytes;
     if (p - base >= size) return false; // not inside an allocation of ours
     return size - (p - base) < bytes;
 }
@@ -166,12 +179,16 @@ panda_error panda_mem_pool_create(panda_mem_pool *pool, int device_id)
     return static_cast<panda_error>(e);
 }
 
-panda_error panda_mem_pool_destroy(panda_mem_pool pool) { return static_cast<panda_error>(hipMemPoolDestroy(static_cast<hipMemPool_t>(pool.handle))); }
+panda_error panda_mem_pool_destroy(panda_mem_pool pool)
+{
+    panda::untrack_pool(pool.handle);
+    return static_cast<panda_error>(hipMemPoolDestroy(static_cast<hipMemPool_t>(pool.handle)));
+}
 
 panda_error panda_malloc_from_pool_async(void **ptr, size_t size, panda_mem_pool pool, panda_stream stream)
 {
     const hipError_t e = hipMallocFromPoolAsync(ptr, size, static_cast<hipMemPool_t>(pool.handle), static_cast<hipStream_t>(stream.handle));
-    if (e == hipSuccess && ptr) panda::track_allocation(*ptr, size);
+    if (e == hipSuccess && ptr) panda::track_allocation(*ptr, size, pool.handle);
     return static_cast<panda_error>(e);
 }
 

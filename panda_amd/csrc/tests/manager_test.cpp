@@ -356,6 +356,14 @@ int main(int argc, char **argv)
         std::vector<uint8_t> b1 = x2, b2 = x3, b3 = x2;
         REQUIRE(mgm.ntt_bn254_batch({b1.data(), b2.data(), b3.data()}, b1.size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
         REQUIRE(b1 == y2 && b2 == y3 && b3 == y2);
+        { // a batch longer than one staging window (eight transforms): windows of 8 + 3
+            std::vector<std::vector<uint8_t>> many;
+            std::vector<uint8_t *> ptrs;
+            for (int t = 0; t < 11; t++) many.push_back(t % 2 ? x3 : x2);
+            for (auto &v : many) ptrs.push_back(v.data());
+            REQUIRE(mgm.ntt_bn254_batch(ptrs, many[0].size(), Bytes{(const uint8_t *)omega, 32}, log_n) == PandaGpuError::Ok);
+            for (int t = 0; t < 11; t++) REQUIRE(many[t] == (t % 2 ? y3 : y2));
+        }
         REQUIRE(mgm.deinit() == PandaGpuError::Ok);
         printf("PandaMultiGpuManager: sharded MSM 2^15 (registered and tabled), NTT 2^13 and a pipelined batch of three from host slices ok\n");
     }
