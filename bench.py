@@ -941,8 +941,9 @@ def ntt_figure(ctx: Ctx, log_n: int = 24, reps: int = 11, sweep: bool = True, fi
     res["metric"] = f"NTT elements/s ({'BLS12-377' if field else 'BN254'} Fr, 2^24, forward)"
     if log_n == 24:
         # what binds the passes: v_mad_u64_u32 per thread (8 elements) and pass in k_ntt_pass8 -- 24.25 butterfly products
-        # (7 of wave 0's 12 middle-block products are skipped) + 8 / 16 / 0 output products of 143 each -- over the transform's device time
-        mads_per_element = (24.25 * 3 + 8 + 16) * 143 / 8
+        # (7 of wave 0's 12 middle-block products are skipped) of 143 each, + 8 output products of 143 in the first pass and 8 Montgomery
+        # products (162 + 9 on the same pipe) from the streamed table in the middle pass -- over the transform's device time
+        mads_per_element = ((24.25 * 3 + 8) * 143 + 8 * 171) / 8
         mads = n24 * mads_per_element / (res["ms"] * 1e-3)
         res["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12, "unit": "T mad lane-ops/s",
                                  "frac": mads / MAD_PEAK_PER_S, "mads_per_element": mads_per_element}

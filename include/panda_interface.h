@@ -228,6 +228,10 @@ panda_error panda_ntt_last_device_ms(float *ms);
  * entries, zero-padded).  *flag of the execute calls is passes & 1.  The bit-reversed orderings run the same number of passes (radix-512
  * passes last for a bit-reversed input) except at 2^18 and 2^27, where they keep the eight-bit plan. */
 panda_error panda_ntt_pass_plan(unsigned log_n, unsigned *passes, unsigned *radix_bits);
+/* Streamed inter-pass table (experiment; 0 = off, the default): the second boundary of a three-pass transform (2^17 .. 2^24 points as
+ * 8 + 8 + x bits) multiplies every element by ONE entry of a table over the whole twiddle index range -- 32 bytes per element of the
+ * transform, built once per root and size, kept in the calling thread's twiddle cache -- instead of by two entries of 2^16-entry tables. */
+panda_error panda_ntt_set_streamed_tables(unsigned on);
 /* Bit-reversed orderings (SURVEY 8f-4 "bit-reversed NTT variants"): the forward transform with y[k] stored at bitrev(k), and the inverse
  * (n^-1 fused) of a buffer in that order back to natural-order coefficients.  Chaining them skips two permutations. */
 panda_error panda_ntt_execute_bn254_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);

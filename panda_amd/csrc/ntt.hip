@@ -26,6 +26,7 @@
 // the caller's all-to-all moves chunk q (k2 in [q m/G, (q+1) m/G)) to rank q; step2 = m/G transforms of
 // size G with root w^m down the received pieces.  Rank q ends with y[k1 m + q m/G + k2'] at [k1][k2'].
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -42,14 +43,15 @@ constexpr int NL = 9;           // limbs of every supported scalar field (BN254 
 constexpr int TW_STRIDE = 12;   // table entries padded to 48 B for 16-byte loads
 constexpr int TILE = 1024;      // elements per workgroup
 
+constexpr int POW_BITS = 24; // exponents of the power tables stay below 2^24 (the streamed inter-pass table of a 2^24-point transform)
 struct PowBase {
-    u32 pw[20][NL]; // base^(2^j), canonical internal form
+    u32 pw[POW_BITS][NL]; // base^(2^j), canonical internal form
     u32 scale[NL];  // optional factor folded into every entry
     int has_scale;
 };
 
 // out[t] = base^e(t) (* scale), canonical, t < count.  e(t) = t, or, for the two-dimensional tables of the wide inter-pass
-// twiddles (rows_deg != 0), e(t) = (t >> rows_deg) * (t & (2^rows_deg - 1)): row a holds base^(a i), i < 2^rows_deg.  e < 2^20.
+// twiddles (rows_deg != 0), e(t) = (t >> rows_deg) * (t & (2^rows_deg - 1)): row a holds base^(a i), i < 2^rows_deg.  e < 2^24.
 template <class Fr>
 __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, unsigned rows_deg, u32 *__restrict__ out)
 {
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) k_pow_table(PowBase pb, unsigned count, u
     } else
         fe_one(acc);
 #pragma unroll
-    for (int j = 0; j < 20; j++) {
+    for (int j = 0; j < POW_BITS; j++) {
         if ((t >> j) & 1) {
 #pragma unroll
             for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(256) k_pow_table2(PowBase pb, unsigned count, 
     } else
         fe_one(acc);
 #pragma unroll
-    for (int j = 0; j < 20; j++) {
+    for (int j = 0; j < POW_BITS; j++) {
         if ((t >> j) & 1) {
 #pragma unroll
             for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
@@ -108,6 +110,32 @@ __global__ void __launch_bounds__(256) k_pow_table2(PowBase pb, unsigned count, 
         dst[NL + i] = tw.q[i];
     }
     dst[2 * NL] = dst[2 * NL + 1] = 0;
+}
+
+// the same powers as 32-byte wire elements in the kernels' own Montgomery radix (w 2^261 mod p, canonical, packed): the streamed table of
+// the middle pass's single output product (Pass8Args::wide)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_pow_table_wire(PowBase pb, unsigned count, unsigned rows_deg, u32 *__restrict__ out)
+{
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const unsigned t = (idx >> rows_deg) * (idx & ((1u << rows_deg) - 1));
+    Fe<Fr> acc, f;
+    fe_one(acc);
+#pragma unroll
+    for (int j = 0; j < POW_BITS; j++) {
+        if ((t >> j) & 1) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) f.l[i] = pb.pw[j][i];
+            fe_mul(acc, acc, f);
+        }
+    }
+    fe_reduce_once(acc);
+    u32 w8[8];
+    fe_pack(w8, acc);
+    uint4 *d4 = reinterpret_cast<uint4 *>(out + (size_t)idx * 8);
+    d4[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+    d4[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
 }
 
 template <class Fr>
@@ -450,22 +478,39 @@ PassPlan plan_passes(unsigned log_n, bool br_in = false, bool br_out = false)
     return pl;
 }
 
+// Streamed inter-pass table (panda_ntt_set_streamed_tables): where a radix-256 pass would multiply its outputs by TWO table entries
+// (the twiddle's index range, 2^(log_p + 8 + deg2), exceeds the 2^16-entry tables: the second boundary of every three-pass transform),
+// it can read ONE 32-byte entry per element from a table over the whole range instead -- as large as the data, streamed beside it,
+// built once per root and size and cached -- and multiply once.
+std::atomic<unsigned> g_streamed_tables{1}; // the policy since round 5: -6 % at 2^20, -4 % at 2^22, -1.4 % at 2^24 (profiles/r05_ntt_streamed_table.txt)
+
+// log2 of the entries of the streamed table of pass j, 0 if that pass does not take one
+unsigned streamed_table_bits(const PassPlan &pl, unsigned j, unsigned log_n, bool allow)
+{
+    if (!allow || pl.wide || log_n < 11 || j + 1 >= pl.count || pl.d[j] != 8) return 0;
+    unsigned log_p = 0;
+    for (unsigned i = 0; i < j; i++) log_p += pl.d[i];
+    const unsigned bits = log_p + 8 + pl.d[j + 1];
+    return (bits > 16 && bits <= (unsigned)POW_BITS) ? bits : 0;
+}
+
 struct PassTables {
     size_t ta, tb, pq;
 };
-PassTables pass_tables(const PassPlan &pl, unsigned j)
+PassTables pass_tables(const PassPlan &pl, unsigned j, unsigned log_n = 0, bool streamed = false)
 {
+    if (const unsigned bits = streamed_table_bits(pl, j, log_n, streamed)) return PassTables{panda::align256((size_t)32 << bits), 256, SZ_PQ};
     if (!pl.wide) return PassTables{SZ_TA, SZ_TB, SZ_PQ};
     const bool last = j + 1 == pl.count;
     return PassTables{last ? 256 : SZ_T18, last ? 256 : SZ_T18, SZ_PQ9};
 }
 // bytes ntt_passes carves out of its arena for a transform of 2^log_n points
-size_t passes_table_bytes(unsigned log_n, bool br_in = false, bool br_out = false)
+size_t passes_table_bytes(unsigned log_n, bool br_in = false, bool br_out = false, bool streamed = false)
 {
     const PassPlan pl = plan_passes(log_n, br_in, br_out);
     size_t total = 0;
     for (unsigned j = 0; j < pl.count; j++) {
-        const PassTables t = pass_tables(pl, j);
+        const PassTables t = pass_tables(pl, j, log_n, streamed);
         total += t.ta + t.tb + t.pq + 3 * 256;
     }
     return total;
@@ -475,7 +520,7 @@ template <class Fr>
 void fill_pow_base(PowBase &pb, const Fe<Fr> &base, const Fe<Fr> *scale)
 {
     Fe<Fr> cur = base;
-    for (int j = 0; j < 20; j++) {
+    for (int j = 0; j < POW_BITS; j++) {
         Fe<Fr> c = cur;
         fe_reduce_once(c);
         for (int i = 0; i < NL; i++) pb.pw[j][i] = c.l[i];
@@ -686,8 +731,11 @@ struct TwiddleCache {
     }
 };
 // one entry per call family, so that the alternating steps of a sharded transform do not evict each other's tables
-enum { TW_WHOLE = 0, TW_SLAB1 = 1, TW_SLAB2 = 2, TW_SLOTS = 3 };
+// (whole transforms get two entries: a prover alternates between a size's forward and inverse transform, and the streamed inter-pass
+// table of a 2^24-point transform is 2^24 twelve-product entries to rebuild)
+enum { TW_WHOLE = 0, TW_WHOLE_B = 1, TW_SLAB1 = 2, TW_SLAB2 = 3, TW_SLOTS = 4 };
 thread_local TwiddleCache g_twiddles[TW_SLOTS];
+thread_local unsigned g_whole_last = 0; // which of the two whole-transform entries was used last
 
 template <class Fr>
 void twiddle_key(u32 (&key)[12], unsigned log_n, unsigned variant, const u32 *omega_wire)
@@ -741,7 +789,7 @@ thread_local PassTimer g_pass_timer;
 // `build` = false reuses the tables already sitting in `arena` (same carve order).
 template <class Fr, class Alloc>
 hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
-                      unsigned *passes_out, bool build = true, bool br_in = false, bool br_out = false)
+                      unsigned *passes_out, bool build = true, bool br_in = false, bool br_out = false, bool streamed = false)
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
@@ -755,7 +803,8 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
     while (log_p < log_n) {
         const unsigned deg = pl.d[passes];
         const bool last = (passes + 1 == total_passes);
-        const PassTables sz = pass_tables(pl, passes);
+        const PassTables sz = pass_tables(pl, passes, log_n, streamed);
+        const unsigned stream_bits = streamed_table_bits(pl, passes, log_n, streamed);
         u32 *d_ta = (u32 *)arena.take(sz.ta), *d_tb = (u32 *)arena.take(sz.tb), *d_pq = (u32 *)arena.take(sz.pq);
         if (!d_ta || !d_tb || !d_pq) return hipErrorOutOfMemory;
         Fe<Fr> base;
@@ -784,11 +833,17 @@ hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst
                     a.cb = log_p + deg - a.ca;
                 }
                 a.i2_shift = log_n - deg2 - log_p - deg;
+                a.wide = stream_bits ? 1u : 0u;
             }
             if (build) {
                 fe_pow_u64(base, omega, n >> full); // butterfly twiddles (w^(n / 2^full))^t
                 build_table2<Fr>(stream, base, nullptr, 1u << (full - 1), d_pq);
-                if (!last) {
+                if (!last && stream_bits) { // [i2][k2], k2 < 2^(log_p + 8): exponent i2 k2 < 2^stream_bits
+                    fe_pow_u64(base, omega, n >> (log_p + deg) >> deg2);
+                    PowBase pb;
+                    fill_pow_base<Fr>(pb, base, nullptr);
+                    hipLaunchKernelGGL(k_pow_table_wire<Fr>, dim3((unsigned)((((u64)1 << stream_bits) + 255) / 256)), dim3(256), 0, stream, pb, 1u << stream_bits, log_p + deg, d_ta);
+                } else if (!last) {
                     fe_pow_u64(base, omega, n >> (log_p + deg) >> deg2);
                     build_table2<Fr>(stream, base, (scale && passes == 0) ? scale : nullptr, 1u << (deg2 + a.ca), d_ta, a.ca);
                     if (a.cb) {
@@ -876,12 +931,20 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (log_n > 28 || !d_src || !d_dst || !omega_wire) return hipErrorInvalidValue;
     if (panda::extent_too_short(d_src, (size_t)32 << log_n) || panda::extent_too_short(d_dst, (size_t)32 << log_n)) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
-    TwiddleCache &tw = g_twiddles[TW_WHOLE];
     u32 key[12];
-    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u), omega_wire); // the bit-reversed orderings may run another plan
-    PANDA_TRY(tw.settle(stream));
+    const bool streamed = g_streamed_tables.load(std::memory_order_relaxed) != 0;
+    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u) | (streamed ? 8u : 0u), omega_wire); // the bit-reversed orderings may run another plan
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
+    // the entry that holds these tables, else the one that was not used last
+    unsigned slot = g_whole_last ^ 1u;
+    for (unsigned c = 0; c < 2; c++) {
+        const TwiddleCache &t = g_twiddles[TW_WHOLE + c];
+        if (t.valid && t.device == dev && memcmp(key, t.key, sizeof(key)) == 0) slot = c;
+    }
+    g_whole_last = slot;
+    TwiddleCache &tw = g_twiddles[TW_WHOLE + slot];
+    PANDA_TRY(tw.settle(stream));
     const bool hit = tw.valid && tw.device == dev && memcmp(key, tw.key, sizeof(key)) == 0;
     Fe<Fr> omega, scale;
     fe_zero(omega);
@@ -889,14 +952,14 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
         fe_from_wire(omega, omega_wire);
         if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in, br_out) + 4096));
+        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in, br_out, streamed) + 4096));
     } else
         tw.used = 0;
     tw.valid = false;
     unsigned passes = 0;
     PassTimer &pt = g_pass_timer;
     PANDA_TRY(pt.begin(stream));
-    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit, br_in, br_out));
+    PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit, br_in, br_out, streamed));
     PANDA_TRY(pt.end(stream));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
@@ -1284,6 +1347,12 @@ panda_error panda_ntt_last_device_ms(float *ms)
 {
     if (!ms) return panda_error_invalid_value;
     *ms = g_pass_timer.ms;
+    return panda_success;
+}
+
+panda_error panda_ntt_set_streamed_tables(unsigned on)
+{
+    g_streamed_tables.store(on ? 1u : 0u, std::memory_order_relaxed);
     return panda_success;
 }
 

@@ -48,6 +48,9 @@ struct Pass8Args {
     unsigned br_in;    // first pass: the caller's input is in bit-reversed order
     unsigned br_out;   // last pass: leave the output in bit-reversed order
     unsigned tiles;    // tiles of the pass (a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...)
+    unsigned wide;     // not the last pass, cb != 0 geometry: the output twiddle W^(i2 k2) comes from ONE table of 2^(deg2 + lgp + 8) entries -- ta, 32 bytes
+                       // each: the twiddle times the kernels' Montgomery radix, in wire limbs -- streamed beside the data ([i2][k2]: a thread's entries
+                       // sit where its outputs sit), and the product is one ordinary Montgomery product instead of two precomputed-quotient ones
     unsigned skip;     // LAST pass only: a pass of radix 2^(8 - skip), skip = 1 .. 4.  The top `skip` bits of the 8-bit local index then
                        // select the sub-transform instead of a position in it (a tile holds 8 << skip sub-transforms) and rounds
                        // 0 .. skip - 1 do not run; the twiddle indices of the remaining rounds are what they were (powers of the
@@ -419,7 +422,32 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass8(Pass8Args A)
         const unsigned i2 = (blk >> lgp) >> A.i2_shift;
         // The table entries of the eight products are fetched one product ahead and no further (a scheduling barrier per element):
         // hoisted all at once they are 160 registers, and the spills that buys showed up as 0.8 GB of scratch traffic per launch
-        if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
+        if (A.wide) { // one streamed table over the whole index range: entry (i2, k2 = i_out 2^lgp + k)
+            // fe_mul wants x tw < 0.9 R p: true as it stands while FB < 0.9 R / p (BN254: 31 of 169, BLS12-377: 7 of 438); BLS12-381 (63 of 70)
+            // first brings x below 2p (one multiply-add chain, which also normalises it)
+            constexpr bool REDUCE_FIRST = (long long)FB * 10 >= (long long)Fr::HEADROOM * 9;
+            const u32 *row = A.ta + (((size_t)i2 << (lgp + 8)) + k + ((size_t)iq << lgp)) * 8;
+            uint4 nlo = reinterpret_cast<const uint4 *>(row)[0], nhi = reinterpret_cast<const uint4 *>(row)[1];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const u32 w8[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
+                if (m + 1 < 8) {
+                    const uint4 *nx = reinterpret_cast<const uint4 *>(row + ((size_t)(br3(m + 1) << 5) << lgp) * 8);
+                    nlo = nx[0];
+                    nhi = nx[1];
+                }
+                Fe<Fr> tw, x, v;
+                fe_unpack(tw, w8);
+                if constexpr (REDUCE_FIRST) {
+                    x = e[m];
+                    fe_reduce_mad_2p(x);
+                } else
+                    fe_norm(x, e[m]); // the last round leaves its outputs un-normalised (limbs < 3 * 2^30): a Montgomery product wants them below 2^30.5
+                fe_mul(v, x, tw); // x < FB p, tw < p: below 0.9 R p; the result is tight and below 2p: it fits the 32-byte element and the next pass's input bound
+                store_elem32(A.y + (base + ((size_t)(br3(m) << 5) << lgp)) * 8, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
             const unsigned row = i2 << A.ca;
             TwV<Fr> nxt;
             load_tw2(nxt, A.ta, row | iq);

@@ -461,6 +461,48 @@ def test_ntt_bit_reversed_orderings(gm, log_n):
     assert (buf == x).all()
 
 
+@pytest.mark.parametrize("cid,log_n", [(0, 19), (0, 20), (0, 21), (1, 20), (2, 20), (0, 23)])
+def test_ntt_streamed_inter_pass_table(gm, cid, log_n):
+    """panda_ntt_set_streamed_tables: the second boundary of a three-pass transform multiplies by ONE entry of a table over the whole
+    index range (a Montgomery product) instead of two 2^16-entry tables' entries -- same outputs, forward and inverse, for the three
+    scalar fields (BLS12-381's R / p = 70 is the tight one); the twiddle cache keeps the two kinds of table apart."""
+    lib = ffi.load()
+    fid = po.FR_OF[cid]
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    fwd = (lib.panda_ntt_execute_bn254_v1, lib.panda_ntt_execute_bls12_377_v1, lib.panda_ntt_execute_bls12_381_v1)[cid]
+    inv = (lib.panda_ntt_execute_bn254_inverse, lib.panda_ntt_execute_bls12_377_inverse, lib.panda_ntt_execute_bls12_381_inverse)[cid]
+    d_a, d_b = DeviceBuffer(n * 32), DeviceBuffer(n * 32)
+    ffi.check(lib.panda_gen_scalars(cid, 0x57AB + log_n, 0, n, d_a.ptr, NULL_STREAM), "gen")
+    x = d_a.to_host().reshape(n, 8)
+    flag = C.c_uint(9)
+    outs = []
+    try:
+        for on in (0, 1, 0, 1):
+            ffi.check(lib.panda_ntt_set_streamed_tables(on), "option")
+            ffi.check(lib.panda_memcpy(d_a.ptr, C.c_void_p(x.ctypes.data), n * 32), "memcpy")
+            cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+            ffi.check(fwd(cfg), "ntt")
+            assert flag.value == ntt_passes(log_n) % 2
+            f, o = (d_b, d_a) if flag.value else (d_a, d_b)
+            outs.append(f.to_host().reshape(n, 8))
+            cfg2 = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, f.ptr, o.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
+            ffi.check(inv(cfg2), "intt")
+            back = (o if flag.value else f).to_host().reshape(n, 8)
+            assert np.array_equal(back, x), on
+    finally:
+        lib.panda_ntt_set_streamed_tables(0)
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    if log_n <= 20:
+        assert np.array_equal(outs[1], po.ntt(fid, x, om, log_n))
+    else:
+        rng = np.random.default_rng(log_n)
+        for k in [0, 1, n - 1] + [int(v) for v in rng.integers(0, n, 5)]:
+            assert (outs[1][k] == po.ntt_eval_at(fid, x, om, log_n, k)).all(), k
+    d_a.free()
+    d_b.free()
+
+
 def test_ntt_setup_then_execute(gm):
     """init_ntt + panda_ntt_bn254_gpu (wrapper.rs:199-210, unit.rs:418-479): omega from the global setup."""
     fid, log_n = po.F_BN254_FR, 11
