@@ -462,6 +462,7 @@ def contract_line(full: dict) -> dict:
         if isinstance(v, (int, float)) and v > 0:
             ms[name] = _sig(v * scale, 4)
 
+    put("c1_host_msm_2_16_cpu", "config1_host_msm_2_16", "ms")
     put("c2_msm_2_20_tables", "config2_msm_2_20", "with_tables", "ms_per_step")
     put("c2_msm_2_20_registered", "config2_msm_2_20", "registered_only", "ms_per_step")
     put("c3_ntt_2_24_fwd", "ntt", "ms")
@@ -728,6 +729,7 @@ def main():
             lambda: small_config(ctx, 1, 24, ctx.ffi.PROJECTIVE, 5, "BLS12-377 MSM 2^24 + Projective-output conversion (BASELINE config 5)"))
         leg("bn254_g2_msm_2_20", lambda: small_config(ctx, 3, 20, ctx.ffi.JACOBIAN, 5, "BN254 G2 MSM 2^20 (SURVEY 8f-4; coordinates in Fq2), Jacobian output, cached bases"))
     if world == 1 and not args.no_cpu_baseline and rank == 0:
+        leg("config1_host_msm_2_16", lambda: config1_host(ctx))
         leg("cpu_baseline", lambda: cpu_baseline(args.cpu_sample_log_n))
     if world > 1 and not args.no_c_abi_leg:
         # the other ranks wait on the HOST (a store key, not a collective: a rank parked in an RCCL barrier would spin on its GPU)
@@ -799,6 +801,42 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
     res["value"] = res["with_tables"]["value"]
     prob.release()
     return res
+
+
+def config1_host(ctx: Ctx, log_n: int = 16) -> dict:
+    """BASELINE config 1: BN254 MSM 2^16 through the CPU host-debug entry point (panda_msm_execute_bn254_host: every pointer a host pointer,
+    unit.rs:363-416 / msm_host.cuh:267-383) -- the product's own CPU path, one thread; the same inputs through the GPU call must give the same
+    affine point (x / z^2, y / z^3 compared with Python integers)"""
+    import numpy as np
+
+    torch, lib, ffi = ctx.torch, ctx.lib, ctx.ffi
+    n = 1 << log_n
+    prob = MsmProblem(ctx, 0, log_n, SEED ^ 0xC1, ffi.JACOBIAN, register=False)
+    prob.execute()
+    gpu = prob.result.cpu().numpy().view(np.uint32).copy()
+    bases, scalars = prob.bases.cpu().numpy(), prob.scalars.cpu().numpy()
+    out = np.zeros(96, dtype=np.uint8)
+    cfg = ffi.MSMConfiguration(ffi.PandaMemPool(), ffi.PandaStream(), bases.ctypes.data, scalars.ctypes.data, out.ctypes.data, log_n, ffi.JACOBIAN)
+    t = time.perf_counter()
+    ffi.check(lib.panda_msm_execute_bn254_host(cfg), "host msm")
+    dt = time.perf_counter() - t
+    p = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+    def affine(w):  # Jacobian X || Y || Z in Montgomery form -> (x, y) up to the common radix factor, None for the identity
+        X, Y, Z = (int.from_bytes(w[8 * i:8 * i + 8].tobytes(), "little") for i in range(3))
+        if Z == 0:
+            return None
+        rinv = pow(1 << 256, -1, p)
+        X, Y, Z = X * rinv % p, Y * rinv % p, Z * rinv % p
+        zi = pow(Z, -1, p)
+        return X * zi * zi % p, Y * zi * zi * zi % p
+
+    same = affine(gpu) == affine(out.view(np.uint32))
+    prob.release()
+    if not same:
+        raise RuntimeError("the CPU entry point and the GPU call disagree on the same inputs")
+    return {"value": n / dt, "unit": "points/s", "ms": dt * 1e3, "cores": 1, "matches_gpu": True,
+            "workload": f"BN254 MSM 2^{log_n} through panda_msm_execute_bn254_host (BASELINE config 1), one host thread"}
 
 
 def plain_windows(lib, curve: int, log_n: int) -> int:
