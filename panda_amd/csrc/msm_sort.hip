@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
     if (q == R.q_hi - 1) cell_off[R.q_hi] = red[0] + sc[t]; // the start of the next launch's first cell (written again, to the same value, by that launch); the list's total at the end
 }
 
-constexpr unsigned K3_THREADS = 1024;
+constexpr unsigned K3_THREADS = 1024; // (512 threads on half-size cells, four workgroups per CU: k3_merge 0.994 -> 0.968 ms at 2^24, k1_scatter_split 0.535 -> 0.590 with its 256 partitions: round 5)
 constexpr unsigned K3_PER = 16;                     // words a thread keeps in registers
 constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once
 

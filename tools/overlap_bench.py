@@ -16,6 +16,10 @@ from panda_amd import gpu_ffi as ffi  # noqa: E402
 from panda_amd import gpu_manager as pgm  # noqa: E402
 
 
+if os.environ.get("PANDA_LIB"):  # timing experiments: another build of the library
+    ffi.LIB_PATH = os.environ["PANDA_LIB"]
+
+
 def main():
     ks = [int(x) for x in sys.argv[1].split(",")]
     combos = [tuple(int(v) for v in x.split(":")) for x in sys.argv[2].split(",")]
