@@ -45,6 +45,11 @@ def main():
         bases = po.gen_bases(cid, seed, n)
         want = po.expected_from_linearity(cid, seed, scalars)
         mode = int(rng.integers(0, 3))
+        # the round-5 options ride along at random: the split sort (any cut, work-queue or plain grid) and the accumulate with its row in LDS
+        ov = (int(rng.integers(1, 128)), int(rng.choice([0, 2, 6, 8, 64]))) if rng.random() < 0.5 else (0, 0)
+        variant = int(rng.integers(0, 3))
+        lib.panda_msm_set_overlap(*ov)
+        lib.panda_msm_set_accumulate_variant(variant)
         if mode == 1:  # registered bases, plain windows: forced widths incl. the three-level sort with a list per window
             lib.panda_msm_set_window_bits(int(rng.choice([0, 12, 16, 17, 19, 20])))
         wb = int(rng.choice([0, 0, 8, 10, 12, 14, 16, 18, 20, 22]))
@@ -67,9 +72,11 @@ def main():
         got = po.to_affine(cid, out.view(np.uint32))
         if not (got == want).all():
             bad += 1
-            print("MISMATCH", dict(cid=cid, k=k, seed=seed, pattern=pattern, mode=mode, wb=wb), flush=True)
+            print("MISMATCH", dict(cid=cid, k=k, seed=seed, pattern=pattern, mode=mode, wb=wb, overlap=ov, variant=variant), flush=True)
         if it % 25 == 24:
             print(f"{it + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    lib.panda_msm_set_overlap(0xFFFFFFFF, 0)
+    lib.panda_msm_set_accumulate_variant(0)
     print(f"done: {cases} cases, {bad} mismatches")
     gm.deinit()
     sys.exit(1 if bad else 0)
