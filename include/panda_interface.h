@@ -251,6 +251,10 @@ panda_error panda_ntt_execute_bls12_377_coset(const panda_ntt_configuration_v1 e
 panda_error panda_ntt_execute_bls12_377_coset_inverse(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
 panda_error panda_ntt_execute_bls12_381_v1(const panda_ntt_configuration_v1 exec_cfg);
 panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_381_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_381_inverse_bitrev_in(const panda_ntt_configuration_v1 exec_cfg);
+panda_error panda_ntt_execute_bls12_381_coset(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
+panda_error panda_ntt_execute_bls12_381_coset_inverse(const panda_ntt_configuration_v1 exec_cfg, const void *shift);
 
 /* Multi-GPU, one process per GPU.  The exchange itself is the caller's (RCCL through
  * torch.distributed or ncclAllGather): these are the per-rank halves either side of it.
@@ -290,6 +294,11 @@ panda_error panda_ntt_slab_step1_bls12_377_enqueue(const panda_ntt_slab_configur
 panda_error panda_ntt_slab_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_inverse_step1_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
 panda_error panda_ntt_slab_inverse_step2_bls12_377_enqueue(const panda_ntt_slab_configuration cfg);
+/* ... and over the BLS12-381 scalar field */
+panda_error panda_ntt_slab_step1_bls12_381_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_step2_bls12_381_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_inverse_step1_bls12_381_enqueue(const panda_ntt_slab_configuration cfg);
+panda_error panda_ntt_slab_inverse_step2_bls12_381_enqueue(const panda_ntt_slab_configuration cfg);
 
 /* Multi-GPU, ONE process (no reference counterpart: msm_cuda.cuh:554-555 pins device 0, wrapper.rs:38 opens one
  * device, binding.rs:54-56 only declares the peer-access symbols).  A panda_multi_gpu owns one host thread, one stream and -- with
@@ -341,6 +350,10 @@ panda_error panda_ntt_execute_bls12_377_multi(panda_multi_gpu mg, const panda_nt
 panda_error panda_ntt_execute_bls12_377_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
 panda_error panda_ntt_execute_bls12_377_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* count x n_dev */, unsigned count);
 panda_error panda_ntt_execute_bls12_377_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count);
+panda_error panda_ntt_execute_bls12_381_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* n_dev */);
+panda_error panda_ntt_execute_bls12_381_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs);
+panda_error panda_ntt_execute_bls12_381_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs /* count x n_dev */, unsigned count);
+panda_error panda_ntt_execute_bls12_381_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count);
 /* per-phase device times of rank's last MSM inside a *_multi call (the workers' panda_msm_last_phase_ms) */
 panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms /* PANDA_MSM_PHASES floats */);
 

@@ -597,6 +597,34 @@ panda_error panda_ntt_execute_bls12_377_inverse_multi_batch(panda_multi_gpu mg, 
         ntt_multi_batch(*handle_of(mg), cfgs, count, panda_ntt_slab_inverse_step1_bls12_377_enqueue, panda_ntt_slab_inverse_step2_bls12_377_enqueue));
 }
 
+// the same sharded transforms over the BLS12-381 scalar field
+panda_error panda_ntt_execute_bls12_381_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(ntt_multi(*handle_of(mg), cfgs, panda_ntt_slab_step1_bls12_381_enqueue, panda_ntt_slab_step2_bls12_381_enqueue));
+}
+
+panda_error panda_ntt_execute_bls12_381_inverse_multi(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        ntt_multi(*handle_of(mg), cfgs, panda_ntt_slab_inverse_step1_bls12_381_enqueue, panda_ntt_slab_inverse_step2_bls12_381_enqueue));
+}
+
+panda_error panda_ntt_execute_bls12_381_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        ntt_multi_batch(*handle_of(mg), cfgs, count, panda_ntt_slab_step1_bls12_381_enqueue, panda_ntt_slab_step2_bls12_381_enqueue));
+}
+
+panda_error panda_ntt_execute_bls12_381_inverse_multi_batch(panda_multi_gpu mg, const panda_ntt_slab_configuration *cfgs, unsigned count)
+{
+    if (!mg.handle) return panda_error_invalid_value;
+    return static_cast<panda_error>(
+        ntt_multi_batch(*handle_of(mg), cfgs, count, panda_ntt_slab_inverse_step1_bls12_381_enqueue, panda_ntt_slab_inverse_step2_bls12_381_enqueue));
+}
+
 panda_error panda_multi_gpu_last_phase_ms(panda_multi_gpu mg, unsigned rank, float *ms)
 {
     if (!mg.handle || !ms || rank >= handle_of(mg)->n) return panda_error_invalid_value;

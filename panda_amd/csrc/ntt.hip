@@ -1343,6 +1343,40 @@ panda_error panda_ntt_execute_bls12_381_inverse(const panda_ntt_configuration_v1
         ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true));
 }
 
+// ... and the same variants over BLS12-381 Fr ("more curves / NTT variants")
+panda_error panda_ntt_execute_bls12_381_bitrev_out(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, false, false, true));
+}
+
+panda_error panda_ntt_execute_bls12_381_inverse_bitrev_in(const panda_ntt_configuration_v1 cfg)
+{
+    return static_cast<panda_error>(
+        ntt_run<Bls381Fr>(static_cast<hipStream_t>(cfg.stream.handle), cfg.d_src, cfg.d_dst, (const u32 *)cfg.d_omega, cfg.log_n, (unsigned *)cfg.flag, true, true, false));
+}
+
+panda_error panda_ntt_execute_bls12_381_coset(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bls381Fr>(cfg, shift, false));
+}
+
+panda_error panda_ntt_execute_bls12_381_coset_inverse(const panda_ntt_configuration_v1 cfg, const void *shift)
+{
+    return static_cast<panda_error>(ntt_coset_run<Bls381Fr>(cfg, shift, true));
+}
+
+panda_error panda_ntt_slab_step1_bls12_381_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step1<Bls381Fr>(cfg, false)); }
+panda_error panda_ntt_slab_step2_bls12_381_enqueue(const panda_ntt_slab_configuration cfg) { return static_cast<panda_error>(slab_step2<Bls381Fr>(cfg, false)); }
+panda_error panda_ntt_slab_inverse_step1_bls12_381_enqueue(const panda_ntt_slab_configuration cfg)
+{
+    return static_cast<panda_error>(slab_step2<Bls381Fr>(cfg, false, true));
+}
+panda_error panda_ntt_slab_inverse_step2_bls12_381_enqueue(const panda_ntt_slab_configuration cfg)
+{
+    return static_cast<panda_error>(slab_inverse_local<Bls381Fr>(cfg, false));
+}
+
 panda_error panda_ntt_last_device_ms(float *ms)
 {
     if (!ms) return panda_error_invalid_value;

@@ -89,6 +89,7 @@ ADDITIVE_SYMBOLS = [
     "panda_ntt_execute_bls12_377_bitrev_out", "panda_ntt_execute_bls12_377_inverse_bitrev_in", "panda_ntt_execute_bls12_377_coset", "panda_ntt_execute_bls12_377_coset_inverse",
     "panda_ntt_slab_step1_bls12_377_enqueue", "panda_ntt_slab_step2_bls12_377_enqueue", "panda_ntt_slab_inverse_step1_bls12_377_enqueue", "panda_ntt_slab_inverse_step2_bls12_377_enqueue",
     "panda_ntt_execute_bls12_377_multi", "panda_ntt_execute_bls12_377_inverse_multi", "panda_ntt_execute_bls12_377_multi_batch", "panda_ntt_execute_bls12_377_inverse_multi_batch",
+    "panda_ntt_execute_bls12_381_bitrev_out", "panda_ntt_execute_bls12_381_inverse_bitrev_in", "panda_ntt_execute_bls12_381_coset", "panda_ntt_execute_bls12_381_coset_inverse", "panda_ntt_slab_step1_bls12_381_enqueue", "panda_ntt_slab_step2_bls12_381_enqueue", "panda_ntt_slab_inverse_step1_bls12_381_enqueue", "panda_ntt_slab_inverse_step2_bls12_381_enqueue", "panda_ntt_execute_bls12_381_multi", "panda_ntt_execute_bls12_381_inverse_multi", "panda_ntt_execute_bls12_381_multi_batch", "panda_ntt_execute_bls12_381_inverse_multi_batch",
 ]
 ALL_SYMBOLS = REFERENCE_SYMBOLS + RUST_ONLY_SYMBOLS + ADDITIVE_SYMBOLS
 
@@ -162,6 +163,8 @@ def load() -> C.CDLL:
         "panda_ntt_execute_bls12_377_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
         "panda_ntt_execute_bls12_377_inverse_multi_batch": [PandaMultiGpu, C.POINTER(NttSlabConfiguration), C.c_uint],
     }
+    for name in [n for n in list(sig) if "bls12_377" in n and n.replace("bls12_377", "bls12_381") in ADDITIVE_SYMBOLS]:
+        sig.setdefault(name.replace("bls12_377", "bls12_381"), sig[name])
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args

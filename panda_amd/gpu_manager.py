@@ -456,17 +456,17 @@ def panda_ntt_bls12_377_gpu_v1(gm: PandaGpuManager, scalars: np.ndarray, omega, 
     return _ntt(gm, scalars, log_n, lib.panda_ntt_execute_bls12_377_inverse if inverse else lib.panda_ntt_execute_bls12_377_v1, omega)
 
 
-def panda_ntt_bls12_377_gpu_bitrev(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False) -> int:
-    """Additive: the bit-reversed orderings of panda_ntt_bn254_gpu_bitrev over the BLS12-377 scalar field."""
+def panda_ntt_bls12_377_gpu_bitrev(gm: PandaGpuManager, scalars: np.ndarray, omega, log_n: int, inverse: bool = False, field: str = "bls12_377") -> int:
+    """Additive: the bit-reversed orderings of panda_ntt_bn254_gpu_bitrev over the BLS12-377 (or, field="bls12_381", BLS12-381) scalar field."""
     lib = ffi.load()
-    return _ntt(gm, scalars, log_n, lib.panda_ntt_execute_bls12_377_inverse_bitrev_in if inverse else lib.panda_ntt_execute_bls12_377_bitrev_out, omega)
+    return _ntt(gm, scalars, log_n, getattr(lib, f"panda_ntt_execute_{field}_inverse_bitrev_in" if inverse else f"panda_ntt_execute_{field}_bitrev_out"), omega)
 
 
-def panda_coset_ntt_bls12_377_gpu(gm: PandaGpuManager, scalars: np.ndarray, omega, shift, log_n: int, inverse: bool = False) -> int:
-    """Additive: coset transform over the BLS12-377 scalar field (as panda_coset_ntt_bn254_gpu)."""
+def panda_coset_ntt_bls12_377_gpu(gm: PandaGpuManager, scalars: np.ndarray, omega, shift, log_n: int, inverse: bool = False, field: str = "bls12_377") -> int:
+    """Additive: coset transform over the BLS12-377 (or BLS12-381) scalar field (as panda_coset_ntt_bn254_gpu)."""
     lib = ffi.load()
     g = _as_bytes(shift)
-    fn = lib.panda_ntt_execute_bls12_377_coset_inverse if inverse else lib.panda_ntt_execute_bls12_377_coset
+    fn = getattr(lib, f"panda_ntt_execute_{field}_coset_inverse" if inverse else f"panda_ntt_execute_{field}_coset")
     return _ntt(gm, scalars, log_n, lambda cfg: fn(cfg, _ptr(g)), omega)
 
 

@@ -288,7 +288,7 @@ class MultiGpu:
         return out
 
     def ntt(self, slabs, scratches, omega, log_n: int, inverse: bool = False, streams=None, field: int = 0):
-        """panda_ntt_execute_{bn254,bls12_377}[_inverse]_multi (field 0 / 1) on device pointers slabs[d] / scratches[d]; returns the flags
+        """panda_ntt_execute_{bn254,bls12_377}[_inverse]_multi (field 0 / 1 / 2) on device pointers slabs[d] / scratches[d]; returns the flags
         (1: rank d's output is in scratches[d])."""
         assert len(slabs) == len(scratches) == self.n
         g = _log2_exact(self.n)
@@ -298,7 +298,8 @@ class MultiGpu:
             ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[d]), C.c_void_p(scratches[d]), C.c_void_p(om.ctypes.data),
                                      log_n, g, d, C.pointer(flags[d])) for d in range(self.n)])
         fn = ((self.lib.panda_ntt_execute_bn254_multi, self.lib.panda_ntt_execute_bn254_inverse_multi),
-              (self.lib.panda_ntt_execute_bls12_377_multi, self.lib.panda_ntt_execute_bls12_377_inverse_multi))[field][1 if inverse else 0]
+              (self.lib.panda_ntt_execute_bls12_377_multi, self.lib.panda_ntt_execute_bls12_377_inverse_multi),
+              (self.lib.panda_ntt_execute_bls12_381_multi, self.lib.panda_ntt_execute_bls12_381_inverse_multi))[field][1 if inverse else 0]
         ffi.check(fn(self.handle, cfgs), "SchedulingErr")
         return [f.value for f in flags]
 
@@ -314,7 +315,8 @@ class MultiGpu:
             ffi.NttSlabConfiguration(streams[d] if streams else ffi.PandaStream(), C.c_void_p(slabs[t][d]), C.c_void_p(scratches[t][d]), C.c_void_p(om.ctypes.data),
                                      log_n, g, d, C.pointer(flags[t][d])) for t in range(count) for d in range(self.n)])
         fn = ((self.lib.panda_ntt_execute_bn254_multi_batch, self.lib.panda_ntt_execute_bn254_inverse_multi_batch),
-              (self.lib.panda_ntt_execute_bls12_377_multi_batch, self.lib.panda_ntt_execute_bls12_377_inverse_multi_batch))[field][1 if inverse else 0]
+              (self.lib.panda_ntt_execute_bls12_377_multi_batch, self.lib.panda_ntt_execute_bls12_377_inverse_multi_batch),
+              (self.lib.panda_ntt_execute_bls12_381_multi_batch, self.lib.panda_ntt_execute_bls12_381_inverse_multi_batch))[field][1 if inverse else 0]
         ffi.check(fn(self.handle, cfgs, count), "SchedulingErr")
         return [[f.value for f in row] for row in flags]
 

@@ -949,7 +949,7 @@ def _sharded_over(devs, transport, what):
                     with _OnDevice(devs[r]):
                         lib.panda_msm_unregister_bases(db[r].ptr)
         else:
-            field = 1 if what == "ntt_bls12_377" else 0
+            field = {"ntt_bls12_377": 1, "ntt_bls12_381": 2}.get(what, 0)
             fid = po.FR_OF[field]
             log_n = 13 + g
             n, m = 1 << log_n, (1 << log_n) >> g
@@ -985,7 +985,7 @@ def _sharded_over(devs, transport, what):
                 b.free()
 
 
-@pytest.mark.parametrize("what", ["msm", "msm_from_host", "ntt", "ntt_batch", "ntt_bls12_377"])
+@pytest.mark.parametrize("what", ["msm", "msm_from_host", "ntt", "ntt_batch", "ntt_bls12_377", "ntt_bls12_381"])
 @pytest.mark.parametrize("where", ["every_device_rccl", "two_loopback_ranks"])
 def test_c_abi_multi_gpu_widens_with_the_box(gm, where, what):
     """The sharded entry points with one rank per DEVICE of the box over RCCL (ncclCommInitAll over several devices, the in-place
@@ -1159,28 +1159,29 @@ def test_ntt_bls12_377_fr(gm, log_n):
     assert (buf == x).all()
 
 
-@pytest.mark.parametrize("log_n", [0, 3, 9, 12, 17, 18, 20])
-def test_ntt_bls12_377_bit_reversed_orderings_and_coset(gm, log_n):
-    """panda_ntt_execute_bls12_377_{bitrev_out,inverse_bitrev_in,coset,coset_inverse}: the BN254 variants' semantics over BLS12-377 Fr."""
-    fid = po.F_BLS377_FR
-    c = pyref.CURVES[1]
+@pytest.mark.parametrize("cid,log_n", [(1, 0), (1, 3), (1, 9), (1, 12), (1, 17), (1, 18), (1, 20), (2, 3), (2, 12), (2, 17), (2, 20)])
+def test_ntt_bls12_377_bit_reversed_orderings_and_coset(gm, cid, log_n):
+    """panda_ntt_execute_bls12_{377,381}_{bitrev_out,inverse_bitrev_in,coset,coset_inverse}: the BN254 variants' semantics over the two BLS scalar fields."""
+    fid = po.FR_OF[cid]
+    c = pyref.CURVES[cid]
+    field = ("", "bls12_377", "bls12_381")[cid]
     n = 1 << log_n
     om = po.root_of_unity(fid, log_n)
     x = po.gen_scalars(fid, 4300 + log_n, n)
     want = po.ntt(fid, x, om, log_n)
     perm = np.array([int(format(k, f"0{log_n}b")[::-1], 2) if log_n else 0 for k in range(n)])
     buf = x.copy()
-    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n)
+    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n, field=field)
     assert (buf[perm] == want).all()  # buf[bitrev(k)] = y[k]
-    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n, inverse=True)
+    pgm.panda_ntt_bls12_377_gpu_bitrev(gm, buf, om, log_n, inverse=True, field=field)
     assert (buf == x).all()
     if log_n <= 12:  # coset: y = NTT(x[j] g^j), g^j by Python integers
         g = pyref.int_to_limbs(7 * c.Rr % c.r, 8)
         pw = np.stack([pyref.int_to_limbs(pow(7, j, c.r) * c.Rr % c.r, 8) for j in range(n)])
         buf = x.copy()
-        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n)
+        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n, field=field)
         assert (buf == po.ntt(fid, po.f_vec(fid, po.OP_MUL, x, pw), om, log_n)).all()
-        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n, inverse=True)
+        pgm.panda_coset_ntt_bls12_377_gpu(gm, buf, om, g, log_n, inverse=True, field=field)
         assert (buf == x).all()
 
 
