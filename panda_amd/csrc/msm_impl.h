@@ -963,9 +963,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
     // One call, whole input at once, with tables: levels 2 and 3 of the sort for the rest of the bucket space run on the helper stream
-    // beside the accumulation of the front (SortSplit, msm_sort.h).  The three ordering events live as long as the host thread.
+    // beside the accumulation of the front (SortSplit, msm_sort.h).  The two ordering events live as long as the host thread.
     struct SplitEvents {
-        hipEvent_t ev[3] = {};
+        hipEvent_t ev[2] = {};
         int device = -1;
         void drop()
         {
@@ -992,9 +992,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         }
         PANDA_TRY(panda::thread_helper_stream(&split.helper));
         split.front_of_128 = tuning.overlap_front;
-        split.ev_level1 = split_events.ev[0];
-        split.ev_front = split_events.ev[1];
-        split.rest_done = split_events.ev[2];
+        split.ev_front = split_events.ev[0];
+        split.rest_done = split_events.ev[1];
     }
 
     struct PhaseEvents { // the per-range events are destroyed on every exit path

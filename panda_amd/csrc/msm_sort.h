@@ -61,13 +61,14 @@ hipError_t msm_sort_plain(hipStream_t stream, Arena &arena, unsigned fr, const v
 // Overlap of the sort's back half with the accumulation (tabled mode; replaces the serial phases of msm_cuda.cuh:611-755).  Level 1
 // partitions every window's entries by the TOP bits of the bucket id, so everything behind it -- level 2, level 3, k_accumulate -- can
 // run per range of level-1 partitions: the buckets are cut at a partition boundary into a FRONT part and the REST.  The front's levels
-// 2 and 3 run on the caller's stream, the rest's on `helper` beside whatever the caller enqueues behind the sort (the accumulation of the
-// front), and `rest_done` is recorded on `helper` when the whole list is sorted.  The entries before pos[cut_cell] and the bucket
-// offsets up to and including off[cut_bucket] are final in the caller's stream order when msm_sort_tabled returns.
+// 2 and 3 run on the caller's stream; the rest's start on `helper` once the front is sorted (`ev_front`) -- beside whatever the caller
+// enqueues behind the sort, i.e. the accumulation of the front -- and `rest_done` is recorded on `helper` when the whole list is sorted.
+// The entries before pos[cut_cell] and the bucket offsets up to and including off[cut_bucket] are final in the caller's stream order when
+// msm_sort_tabled returns.  Measured on MI355X and not the library's policy (profiles/r05_overlap_sort_accumulate.txt).
 struct SortSplit {
     hipStream_t helper;          // in: second stream (nullptr: no split)
     unsigned front_of_128;       // in: size of the front part, in 1/128 of the bucket space (rounded to what the geometry allows)
-    hipEvent_t ev_level1, ev_front, rest_done; // in: three events the caller owns (no timing needed)
+    hipEvent_t ev_front, rest_done; // in: two events the caller owns (no timing needed)
     bool active;                 // out: the sort was split (false: sizes too small for it; everything ran on the caller's stream)
     const uint32_t *pos;         // out: position of every level-3 cell's first entry in the list, pos[cells] = number of entries
     unsigned cells, cut_cell;    // out: cells in all, first cell of the rest
