@@ -593,6 +593,8 @@ def launch_ranks(args, argv=None, run=None) -> int:
         why = f"torch.distributed.run ended with rc {rc} and no contract line"
     print(f"bench.py: {why}; measuring the {args.gpus} devices through the single-process C entry points", file=sys.stderr, flush=True)
     keep = [a for a in argv if a != "--no-c-abi-leg"]
+    if "--all-on-device0" in keep and "--loopback" not in keep:
+        keep.append("--loopback")  # the rehearsal's one device plays every rank there too
     rc, _ = child([sys.executable, me] + keep + ["--single-process", "--launcher-note", why])
     return rc
 
