@@ -43,7 +43,7 @@ constexpr int NL = 9;           // limbs of every supported scalar field (BN254 
 constexpr int TW_STRIDE = 12;   // table entries padded to 48 B for 16-byte loads
 constexpr int TILE = 1024;      // elements per workgroup
 
-constexpr int POW_BITS = 24; // exponents of the power tables stay below 2^24 (the streamed inter-pass table of a 2^24-point transform)
+constexpr int POW_BITS = 26; // exponents of the power tables stay below 2^26 (the streamed inter-pass table of a 2^26-point transform: 2 GiB)
 struct PowBase {
     u32 pw[POW_BITS][NL]; // base^(2^j), canonical internal form
     u32 scale[NL];  // optional factor folded into every entry
@@ -487,11 +487,11 @@ std::atomic<unsigned> g_streamed_tables{1}; // the policy since round 5: -6 % at
 // log2 of the entries of the streamed table of pass j, 0 if that pass does not take one
 unsigned streamed_table_bits(const PassPlan &pl, unsigned j, unsigned log_n, bool allow)
 {
-    if (!allow || pl.wide || log_n < 11 || j + 1 >= pl.count || pl.d[j] != 8) return 0;
+    if (!allow || log_n < 11 || j + 1 >= pl.count || (pl.d[j] != 8 && pl.d[j] != 9)) return 0;
     unsigned log_p = 0;
     for (unsigned i = 0; i < j; i++) log_p += pl.d[i];
-    const unsigned bits = log_p + 8 + pl.d[j + 1];
-    return (bits > 16 && bits <= (unsigned)POW_BITS) ? bits : 0;
+    const unsigned bits = log_p + pl.d[j] + pl.d[j + 1], cap = pl.wide ? 18u : 16u; // up to 2^cap entries the pass reads one table anyway
+    return (bits > cap && bits <= (unsigned)POW_BITS) ? bits : 0;
 }
 
 struct PassTables {
@@ -499,7 +499,7 @@ struct PassTables {
 };
 PassTables pass_tables(const PassPlan &pl, unsigned j, unsigned log_n = 0, bool streamed = false)
 {
-    if (const unsigned bits = streamed_table_bits(pl, j, log_n, streamed)) return PassTables{panda::align256((size_t)32 << bits), 256, SZ_PQ};
+    if (const unsigned bits = streamed_table_bits(pl, j, log_n, streamed)) return PassTables{panda::align256((size_t)32 << bits), 256, pl.wide ? SZ_PQ9 : SZ_PQ};
     if (!pl.wide) return PassTables{SZ_TA, SZ_TB, SZ_PQ};
     const bool last = j + 1 == pl.count;
     return PassTables{last ? 256 : SZ_T18, last ? 256 : SZ_T18, SZ_PQ9};

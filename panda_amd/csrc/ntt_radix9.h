@@ -189,7 +189,30 @@ __global__ void __launch_bounds__(THREADS, MINW) k_ntt_pass9(Pass8Args A)
         }
     } else {
         const unsigned i2 = (blk >> lgp) >> A.i2_shift;
-        if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
+        if (A.wide) { // one streamed table over the whole index range, one Montgomery product (see k_ntt_pass8)
+            constexpr bool REDUCE_FIRST = (long long)FB * 10 >= (long long)Fr::HEADROOM * 9;
+            const u32 *row = A.ta + (((size_t)i2 << (lgp + 9)) + k + ((size_t)iq << lgp)) * 8;
+            uint4 nlo = reinterpret_cast<const uint4 *>(row)[0], nhi = reinterpret_cast<const uint4 *>(row)[1];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const u32 w8[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
+                if (m + 1 < 8) {
+                    const uint4 *nx = reinterpret_cast<const uint4 *>(row + ((size_t)(br3(m + 1) << 6) << lgp) * 8);
+                    nlo = nx[0];
+                    nhi = nx[1];
+                }
+                Fe<Fr> tw, x, v;
+                fe_unpack(tw, w8);
+                if constexpr (REDUCE_FIRST) {
+                    x = e[m];
+                    fe_reduce_mad_2p(x);
+                } else
+                    fe_norm(x, e[m]);
+                fe_mul(v, x, tw);
+                store_elem32(A.y + (base + ((size_t)(br3(m) << 6) << lgp)) * 8, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (A.cb == 0) { // one table: lgp == 0, k2 = i_out
             const unsigned row = i2 << A.ca;
             TwV<Fr> nxt;
             load_tw2(nxt, A.ta, row | iq);

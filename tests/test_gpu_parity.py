@@ -461,7 +461,7 @@ def test_ntt_bit_reversed_orderings(gm, log_n):
     assert (buf == x).all()
 
 
-@pytest.mark.parametrize("cid,log_n", [(0, 19), (0, 20), (0, 21), (1, 20), (2, 20), (0, 23)])
+@pytest.mark.parametrize("cid,log_n", [(0, 19), (0, 20), (0, 21), (1, 20), (2, 20), (0, 23), (0, 25)])
 def test_ntt_streamed_inter_pass_table(gm, cid, log_n):
     """panda_ntt_set_streamed_tables: the second boundary of a three-pass transform multiplies by ONE entry of a table over the whole
     index range (a Montgomery product) instead of two 2^16-entry tables' entries -- same outputs, forward and inverse, for the three
