@@ -932,7 +932,7 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (panda::extent_too_short(d_src, (size_t)32 << log_n) || panda::extent_too_short(d_dst, (size_t)32 << log_n)) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
     u32 key[12];
-    const bool streamed = g_streamed_tables.load(std::memory_order_relaxed) != 0;
+    bool streamed = g_streamed_tables.load(std::memory_order_relaxed) != 0;
     twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u) | (streamed ? 8u : 0u), omega_wire); // the bit-reversed orderings may run another plan
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
@@ -952,7 +952,15 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
         fe_from_wire(omega, omega_wire);
         if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-        PANDA_TRY(tw.ensure(passes_table_bytes(log_n, br_in, br_out, streamed) + 4096));
+        hipError_t got = tw.ensure(passes_table_bytes(log_n, br_in, br_out, streamed) + 4096);
+        if (got == hipErrorOutOfMemory && streamed) {
+            // no room for a table as large as the data: the transform runs with the two small tables, as it did before round 5
+            (void)hipGetLastError();
+            streamed = false;
+            twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u), omega_wire);
+            got = tw.ensure(passes_table_bytes(log_n, br_in, br_out, false) + 4096);
+        }
+        PANDA_TRY(got);
     } else
         tw.used = 0;
     tw.valid = false;
