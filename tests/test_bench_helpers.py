@@ -145,3 +145,24 @@ def test_bench_starts_its_own_ranks_on_the_gpu_box():
     assert line["n_gpus"] == 2 and line["value"] > 0 and "launcher" not in line
     for k in ("c4_msm_2_26_total", "ntt_sharded_2_24_total", "ntt_sharded_2_24_per_gpu", "c_abi_msm_2_24_per_gpu"):
         assert line["configs_ms"].get(k, 0) > 0, (k, line["configs_ms"])
+
+
+def test_contract_line_of_a_multi_gpu_record():
+    """at N > 1 the flat block carries the strong-scaling legs and the single-process C-ABI leg's figures"""
+    import json
+
+    b = _bench()
+    full = {"metric": "MSM points/s (BN254, 2^24)", "value": 7.4e9, "unit": "points/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 18.1, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "w", "curve": "bn254", "log_points_per_gpu": 24, "bases": "cached", "sharding": "base-range x8", "exchange": "all-gather of 96 B partials (RCCL) + host point additions"},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": 112.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.014, "traffic": None, "kernel_ms": 14.3},
+            "config4_msm_2_26": {"ms_per_step": 9.9, "n_gpus": 8, "log_points_per_gpu": 23, "scaling": "strong"},
+            "ntt_sharded": {"strong_2_24_total": {"ms": 0.6, "inverse_ms": 0.61}, "weak_2_24_per_gpu": {"ms": 2.4}, "value": 2.8e10},
+            "c_abi_single_process": {"ms_per_step": 18.3, "configs_ms": {"c4_msm_2_26_total": 10.1, "ntt_sharded_2_24_total": 0.7, "msm_2_24_from_host_one_call": 21.0}},
+            "soft_failed_legs": []}
+    line = b.contract_line(full)
+    cm = line["configs_ms"]
+    assert cm == {"c4_msm_2_26_total": 9.9, "ntt_sharded_2_24_total": 0.6, "ntt_sharded_2_24_total_inv": 0.61, "ntt_sharded_2_24_per_gpu": 2.4, "c_abi_msm_2_24_per_gpu": 18.3,
+                  "c_abi_c4_msm_2_26_total": 10.1, "c_abi_ntt_sharded_2_24_total": 0.7, "c_abi_msm_2_24_from_host": 21.0}
+    assert line["c4_shape"] == {"n_gpus": 8, "log_points_per_gpu": 23, "scaling": "strong"} and line["n_gpus"] == 8
+    assert len(json.dumps(line)) < 3000
