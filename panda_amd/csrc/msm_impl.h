@@ -1089,7 +1089,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         // (no zero-fill of the bucket array: the first range's fix-up writes the identity into its empty buckets; k_accumulate empties the
         // fix-up's queue of long buckets)
         if (split.active) {
-            // the front of the list, in a grid small enough to leave room on every CU, while the helper stream sorts the rest; then the rest
+            // the front of the list while the helper stream sorts the rest -- as the ordinary grid (overlap_wgs = 64) or as a few workgroups per
+            // CU that draw their chunks from a counter and leave the second stream room --, then the rest
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, registration->device);
             const unsigned all_wgs = (g.chunks + 127) / 128, persist_wgs = std::min((unsigned)cus * overlap_wgs, all_wgs);
@@ -1101,8 +1102,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             else {
                 PANDA_TRY(hipMemsetAsync(d_queue, 0, 4, ls));
                 if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
-                    // the kernel with its row staged in LDS, built for 96 registers: 8 workgroups per CU (4 waves per SIMD) leave 128 per SIMD (and 96 KB of LDS) to the sort's
-                    // 1024-thread workgroups of at most 24 registers
+                    // the kernel with its row staged in LDS, built for 96 registers: 8 workgroups per CU (4 waves per SIMD) leave 128 registers per
+                    // SIMD and 96 KB of LDS to the sort's workgroups (of which only the four-wave ones are placed beside it: profiles/r05_overlap_*)
                     hipLaunchKernelGGL((k_accumulate<Fq, true, 5, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
                                        g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, front);
                 else
