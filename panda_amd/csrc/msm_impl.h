@@ -1096,10 +1096,16 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             const unsigned all_wgs = (g.chunks + 127) / 128, persist_wgs = std::min((unsigned)cus * overlap_wgs, all_wgs);
             u32 *d_queue = d_stale + 16; // a word of the flag block
             const AccPart front{split.pos, 0u, split.cut_cell, 0u, split.cut_bucket, d_queue};
-            if (persist_wgs == all_wgs)
-                hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K, g.chunks,
-                                   d_lcount, registered ? d_stale : nullptr, front);
-            else {
+            if (persist_wgs == all_wgs) {
+                // the ordinary grid; for the 9-limb fields the kernel with its row staged in LDS: 104 registers x 4 waves per SIMD, as fast as the
+                // built-in one (profiles/r05_accumulate_lds_row.txt), leave 96 registers per SIMD to the second stream's four-wave workgroups
+                if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
+                    hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                else
+                    hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+            } else {
                 PANDA_TRY(hipMemsetAsync(d_queue, 0, 4, ls));
                 if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
                     // the kernel with its row staged in LDS, built for 96 registers: 8 workgroups per CU (4 waves per SIMD) leave 128 registers per
@@ -1110,9 +1116,13 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
                     hipLaunchKernelGGL((k_accumulate<Fq, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
                                        g.chunks, d_lcount, registered ? d_stale : nullptr, front);
             }
+            // the rest is accumulated on the HELPER stream, straight behind its sort: the two accumulate launches touch disjoint chunks, pieces and
+            // buckets, so the second one's workgroups fill the CUs as the first one's last round drains (on one stream every launch boundary
+            // costs about half a workgroup's lifetime -- 128 additions, 2.3 ms -- of a half-empty chip); the fix-up waits for both
+            hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, 1), dim3(128), 0, split.helper, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
+                               g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB, nullptr});
+            PANDA_TRY(hipEventRecord(split.rest_done, split.helper));
             PANDA_TRY(hipStreamWaitEvent(ls, split.rest_done, 0));
-            hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
-                               g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB, nullptr});
         } else if (Fq::N <= 9 && !IsExt2<Fq>::value && tuning.acc_variant == 1) {
             if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // five waves per SIMD, the next row staged in LDS (experiment: panda_msm_set_accumulate_variant)
                 hipLaunchKernelGGL((k_accumulate<Fq, false, 5, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,

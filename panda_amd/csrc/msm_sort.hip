@@ -256,11 +256,12 @@ __global__ void __launch_bounds__(1024) k_part_offsets(const u32 *__restrict__ t
     if (t == 1023) part_off[(u64)w * (g.H + 1) + g.H] = tot[1023];
 }
 
-// block-wide exclusive scan of `count` LDS words in place by SORT_THREADS threads
-__device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32 *scratch /* SORT_THREADS words */)
+// block-wide exclusive scan of `count` LDS words in place by THREADS threads
+template <unsigned THREADS = SORT_THREADS>
+__device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32 *scratch /* THREADS words */)
 {
     const unsigned tid = threadIdx.x;
-    const unsigned per = (count + SORT_THREADS - 1) / SORT_THREADS;
+    const unsigned per = (count + THREADS - 1) / THREADS;
     u32 local = 0;
     for (unsigned j = 0; j < per; j++) {
         unsigned i = tid * per + j;
@@ -268,7 +269,7 @@ __device__ __forceinline__ void block_exclusive_scan(u32 *a, unsigned count, u32
     }
     scratch[tid] = local;
     __syncthreads();
-    for (unsigned d = 1; d < SORT_THREADS; d <<= 1) {
+    for (unsigned d = 1; d < THREADS; d <<= 1) {
         u32 v = (tid >= d) ? scratch[tid - d] : 0;
         __syncthreads();
         scratch[tid] += v;
@@ -621,7 +622,10 @@ __global__ void __launch_bounds__(256) k2_offsets(const u32 *__restrict__ totals
 }
 
 // level-2 scatter: the u32 halves of the level-1 words, grouped by their u8 halves within the segment
-__global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict__ p1_lo, const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off,
+// THREADS = 256 (a wave per SIMD): the variant that finds room BESIDE the bucket accumulation when it runs for the rest of a split sort
+// (sixteen-wave workgroups are only placed when accumulate workgroups retire: profiles/r05_overlap_sort_accumulate.txt)
+template <unsigned THREADS>
+__global__ void __launch_bounds__(THREADS) k2_scatter(const u32 *__restrict__ p1_lo, const unsigned char *__restrict__ p1_hi, const u32 *__restrict__ part_off,
                                                   const u32 *__restrict__ seg_tile, const u32 *__restrict__ tile_hist, const u32 *__restrict__ tile_pref,
                                                   const u32 *__restrict__ sub_off, u32 *__restrict__ p2, TabledGeom g, SortRange R)
 {
@@ -630,7 +634,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
     __shared__ u64 gbase[256];
     __shared__ u32 words[SORT_TILE];
     __shared__ unsigned char parts_of[SORT_TILE];
-    __shared__ u32 scratch[SORT_THREADS];
+    __shared__ u32 scratch[THREADS];
     const unsigned tid = threadIdx.x;
     unsigned tile;
     TileRange r;
@@ -641,11 +645,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
         if (tid < g.H2) gbase[tid] = r.seg_begin + sub_off[(u64)r.s * (g.H2 + 1) + tid] + tile_pref[(u64)tile * g.H2 + tid];
     }
     __syncthreads();
-    block_exclusive_scan(lstart, g.H2, scratch);
+    block_exclusive_scan<THREADS>(lstart, g.H2, scratch);
     // 16 entries per thread and step: one aligned 16-byte vector of keys and the four 16-byte vectors of words that go with
     // it (both arrays are padded, entries outside the tile are skipped by index)
     const u64 first = r.begin & ~(u64)15;
-    for (u64 a = first + (u64)tid * 16; a < r.end; a += (u64)SORT_THREADS * 16) {
+    for (u64 a = first + (u64)tid * 16; a < r.end; a += (u64)THREADS * 16) {
         const uint4 kv = *reinterpret_cast<const uint4 *>(p1_hi + a);
         const u32 keys[4] = {kv.x, kv.y, kv.z, kv.w};
         const uint4 *lo4 = reinterpret_cast<const uint4 *>(p1_lo + a);
@@ -667,7 +671,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k2_scatter(const u32 *__restrict
     }
     __syncthreads();
     const u32 total = (u32)(r.end - r.begin);
-    for (u32 j = tid; j < total; j += SORT_THREADS) {
+    for (u32 j = tid; j < total; j += THREADS) {
         u32 h = parts_of[j];
         p2[gbase[h] + (j - lstart[h])] = words[j];
     }
@@ -720,31 +724,41 @@ __global__ void __launch_bounds__(1024) k3_cell_counts(const u32 *__restrict__ s
     }
 }
 
-// cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block
+// cell_off[q] = entries of all earlier cells: earlier blocks (blk_sum) + exclusive scan inside the block of 1024 cells.  blockDim.x = 1024
+// (a cell per thread) or 256 (four consecutive cells per thread: the launch that has to find room beside the bucket accumulation).
 __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ cell_cnt, const u32 *__restrict__ blk_sum, u32 *__restrict__ cell_off, TabledGeom g, SortRange R)
 {
     __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
     __shared__ u32 red[1024];
     __shared__ u32 sc[1024];
-    const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x, q = blk * 1024 + t;
+    const unsigned blk = R.q_lo / 1024 + blockIdx.x, t = threadIdx.x, T = blockDim.x, per = 1024 / T;
     u32 v = 0;
-    for (unsigned b = t; b < blk; b += 1024) v += blk_sum[b]; // the blocks of earlier launches included: their counts are complete (stream / event order)
+    for (unsigned b = t; b < blk; b += T) v += blk_sum[b]; // the blocks of earlier launches included: their counts are complete (stream / event order)
     red[t] = v;
-    const u32 mine = q < R.q_hi ? cell_cnt[q] : 0;
-    sc[t] = mine;
+    const unsigned q0 = blk * 1024 + t * per;
+    u32 local = 0;
+    for (unsigned j = 0; j < per; j++) local += q0 + j < R.q_hi ? cell_cnt[q0 + j] : 0;
+    sc[t] = local;
     __syncthreads();
-    for (unsigned s = 512; s > 0; s >>= 1) {
+    for (unsigned s = T >> 1; s > 0; s >>= 1) {
         if (t < s) red[t] += red[t + s];
         __syncthreads();
     }
-    for (unsigned d = 1; d < 1024; d <<= 1) {
+    for (unsigned d = 1; d < T; d <<= 1) {
         u32 u = (t >= d) ? sc[t - d] : 0;
         __syncthreads();
         sc[t] += u;
         __syncthreads();
     }
-    if (q < R.q_hi) cell_off[q] = red[0] + sc[t] - mine;
-    if (q == R.q_hi - 1) cell_off[R.q_hi] = red[0] + sc[t]; // the start of the next launch's first cell (written again, to the same value, by that launch); the list's total at the end
+    u32 run = red[0] + sc[t] - local;
+    for (unsigned j = 0; j < per; j++) {
+        const unsigned q = q0 + j;
+        if (q < R.q_hi) {
+            cell_off[q] = run;
+            run += cell_cnt[q];
+            if (q == R.q_hi - 1) cell_off[R.q_hi] = run; // the start of the next launch's first cell (written again, to the same value, by that launch); the list's total at the end
+        }
+    }
 }
 
 constexpr unsigned K3_THREADS = 1024; // (512 threads on half-size cells, four workgroups per CU: k3_merge 0.994 -> 0.968 ms at 2^24, k1_scatter_split 0.535 -> 0.590 with its 256 partitions: round 5)
@@ -891,12 +905,16 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
 // image (or, for an oversized cell, straight into the list) -- instead of sixteen words and their ranks held in registers.  A
 // 1024-thread workgroup of it fits the 96 registers per SIMD that the bucket accumulation with its row staged in LDS leaves free, so the
 // rest of the list can be merged BESIDE the accumulation of its front (SortSplit).  Two LDS atomics per entry instead of one.
-__global__ void __launch_bounds__(K3_THREADS) k3_merge_small(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
-                                                    const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
+// THREADS = 256 (a wave per SIMD, placed at once beside resident accumulate workgroups) ranks straight into the list: no 64 KB LDS image, so
+// several of these workgroups fit a CU; the 4-byte stores of a cell land in its own 48 KB of the list.
+template <unsigned THREADS>
+__global__ void __launch_bounds__(THREADS) k3_merge_small(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
+                                                 const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
 {
     __builtin_amdgcn_s_setprio(3); // beside the bucket accumulation of a split sort (SortSplit) these waves must win the issue arbitration: they issue little, it issues always
+    constexpr bool STAGED = THREADS >= 1024;
     __shared__ u32 cnt[128], cur[128], scan_carry;
-    __shared__ u32 outbuf[K3_CAP];
+    __shared__ u32 outbuf[STAGED ? K3_CAP : 1];
     __shared__ u32 rbegin_lo[64], vstart[65]; // a run's start in p2 as (k << log_n) + rbegin_lo[k]
     const unsigned tid = threadIdx.x;
     const unsigned q = R.q_lo + blockIdx.x;
@@ -929,10 +947,10 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge_small(const u32 *__restri
         if (q == g.Q - 1 && tid == 0) off[NB] = out_rel;
         return;
     }
-    // pass 1: count.  A thread's positions grow by K3_THREADS, about one run: the run index only ever steps forward
+    // pass 1: count.  A thread's positions grow by THREADS, at most about one run: the run index only ever steps forward
     unsigned k = 0;
 #pragma unroll 1
-    for (u32 p = tid; p < N; p += K3_THREADS) {
+    for (u32 p = tid; p < N; p += THREADS) {
         while (p >= vstart[k + 1]) k++;
         atomicAdd(&cnt[p2[((u64)k << g.log_n) + rbegin_lo[k] + (p - vstart[k])] >> shift], 1u);
     }
@@ -947,11 +965,11 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge_small(const u32 *__restri
     if (q == g.Q - 1 && tid == 0) off[NB] = out_rel + N;
     __syncthreads();
     // pass 2: the same words again (L2), each to the next free slot of its bucket
-    const bool in_lds = N <= K3_CAP;
+    const bool in_lds = STAGED && N <= K3_CAP;
     const u32 id_mask = (1u << g.log_n) - 1;
     k = 0;
 #pragma unroll 1
-    for (u32 p = tid; p < N; p += K3_THREADS) {
+    for (u32 p = tid; p < N; p += THREADS) {
         while (p >= vstart[k + 1]) k++;
         const u32 v = p2[((u64)k << g.log_n) + rbegin_lo[k] + (p - vstart[k])];
         const u32 word = ((v & id_mask) + g.row0 + (k << g.row_shift)) | (((v >> g.log_n) & 1u) << 31);
@@ -964,7 +982,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge_small(const u32 *__restri
     if (!in_lds) return;
     __syncthreads();
 #pragma unroll 1
-    for (u32 p = tid; p < N; p += K3_THREADS) sorted[out_rel + p] = outbuf[p];
+    for (u32 p = tid; p < N; p += THREADS) sorted[out_rel + p] = outbuf[p];
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -1239,17 +1257,20 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
         hipLaunchKernelGGL(k2_hist, dim3(g.max_tiles2), dim3(256), 0, s, d_p1_hi, d_poff, d_segtile, d_thist2, g, R);
         hipLaunchKernelGGL(k2_scan_cols, dim3((g.H2 + 3) / 4, R.s_hi - R.s_lo), dim3(256), 0, s, d_thist2, d_tpref2, d_segtile, d_tot2, g, R);
         hipLaunchKernelGGL(k2_offsets, dim3(R.s_hi - R.s_lo), dim3(256), 0, s, d_tot2, d_suboff, g, R);
-        hipLaunchKernelGGL(k2_scatter, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
+        if (s == stream)
+            hipLaunchKernelGGL(k2_scatter<SORT_THREADS>, dim3(g.max_tiles2), dim3(SORT_THREADS), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
+        else
+            hipLaunchKernelGGL(k2_scatter<256>, dim3(g.max_tiles2), dim3(256), 0, s, d_p1_lo, d_p1_hi, d_poff, d_segtile, d_thist2, d_tpref2, d_suboff, d_p2, g, R);
     };
     auto level3_counts = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
     };
     auto level3_merge = [&](hipStream_t s, const SortRange &R) {
-        hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(1024), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
+        hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
         if (s == stream)
             hipLaunchKernelGGL(k3_merge, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
         else // on the helper stream, beside the accumulation of the front: the variant that fits next to it
-            hipLaunchKernelGGL(k3_merge_small, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
+            hipLaunchKernelGGL(k3_merge_small<256>, dim3(R.q_hi - R.q_lo), dim3(256), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
     };
     // the cut between the front and the rest: a level-1 partition boundary whose first cell starts a block of 1024 cells
     unsigned cut_h1 = 0;
