@@ -503,11 +503,13 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
             const u32 start = t * K;
             u32 end = start + K;
             bool mine = t < chunks && start < limit;
+            bool clamped = false;
             if (end > limit) {
                 mine = mine && takes_short_chunk;
                 end = limit;
+                clamped = true; // the list's last, short chunk: no earlier launch took it (they only take whole chunks), even if it ends AT lo_pos
             }
-            if (mine && end > lo_pos) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
+            if (mine && (end > lo_pos || clamped)) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
         }
     } else {
         const unsigned t = t0;
@@ -515,11 +517,15 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
         const u32 start = t * K;
         if (start >= limit) return;
         u32 end = start + K;
+        bool clamped = false;
         if (end > limit) {
-            if (!takes_short_chunk) return; // ends among entries a later launch owns
+            if (!takes_short_chunk) return; // ends among entries a later launch owns -- or is the list's last, short chunk, which the last launch takes
             end = limit;
+            clamped = true;
         }
-        if (end > lo_pos) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
+        // (a short last chunk may end exactly at lo_pos -- everything lies in the earlier launch's part -- and still belongs here: the earlier
+        // launch only took whole chunks)
+        if (end > lo_pos || clamped) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
     }
 }
 

@@ -1497,7 +1497,8 @@ def test_msm_precomputed_tables_skewed_2_15(gm, kind):
     (0, 13, 19, 64, 6, "uniform"), (0, 15, 20, 32, 4, "uniform"), (0, 16, 22, 8, 6, "uniform"), (0, 16, 22, 120, 2, "uniform"), (0, 14, 21, 1, 64, "uniform"),
     (0, 14, 22, 40, 6, "zeros"), (0, 14, 22, 40, 6, "ones"), (0, 14, 22, 40, 6, "minus_one"), (0, 14, 22, 40, 6, "small"), (0, 14, 22, 40, 6, "all_equal"),
     (0, 14, 22, 40, 6, "half_zero"), (0, 14, 22, 40, 6, "top_bit"), (0, 18, 22, 32, 6, "uniform"), (0, 20, 0, 32, 6, "uniform"), (1, 14, 20, 32, 0, "uniform"),
-    (2, 13, 19, 64, 0, "uniform")])
+    (2, 13, 19, 64, 0, "uniform"), (1, 2, 22, 121, 8, "uniform"), (1, 2, 20, 113, 6, "uniform"), (0, 3, 22, 100, 64, "uniform"), (0, 5, 21, 127, 8, "uniform"),
+    (0, 6, 22, 64, 64, "small_tiny")])
 def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, wbits, front, wgs, kind):
     """panda_msm_set_overlap: with tables, levels 2 and 3 of the sort for the back of the bucket space run on a second stream beside the
     accumulation of the front (a launch of a few workgroups per CU), then the rest is accumulated.  Same group element as the oracle
@@ -1512,6 +1513,10 @@ def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, w
     ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
     if kind == "uniform":
         ffi.check(lib.panda_gen_scalars(cid, 0x5CA1AB + k, 0, n, ds.ptr, NULL_STREAM), "gen")
+    elif kind == "small_tiny":  # a handful of entries, all in the front part: the list's only chunk is short and ends where the rest begins
+        c0 = pyref.CURVES[0]
+        tiny = np.stack([pyref.int_to_limbs((3 + j) * c0.Rr % c0.r, 8) for j in range(n)])
+        ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(tiny.ctypes.data), n * 32), "memcpy")
     else:
         ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(np.ascontiguousarray(_edge_scalars(kind, n)).ctypes.data), n * 32), "memcpy")
     scalars = ds.to_host().reshape(n, 8)
