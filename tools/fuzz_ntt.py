@@ -24,7 +24,10 @@ def main():
     t0 = time.time()
     for it in range(cases):
         fid = [po.F_BN254_FR, po.F_BLS377_FR, po.F_BLS381_FR][int(rng.integers(0, 3))]
-        k = int(rng.integers(0, 19))
+        k = int(rng.integers(0, 22))  # up to 2^21: the three-pass plans and their streamed inter-pass table included
+        from panda_amd import gpu_ffi as _ffi
+        streamed = int(rng.integers(0, 2))
+        _ffi.load().panda_ntt_set_streamed_tables(streamed)  # flips at random: the two kinds of table share the thread's two cache entries
         om = po.root_of_unity(fid, k)
         x = po.gen_scalars(fid, int(rng.integers(1, 1 << 40)), 1 << k)
         if rng.random() < 0.2:
@@ -56,10 +59,12 @@ def main():
                 ok = ok and all((back[r].cpu().numpy().view(np.uint32).reshape(m, 8) == multi_gpu.slab_of(x, G, r)).all() for r in range(G))
         if not ok:
             bad += 1
-            print("MISMATCH", dict(fid=fid, k=k), flush=True)
+            print("MISMATCH", dict(fid=fid, k=k, streamed=streamed), flush=True)
         if it % 25 == 24:
             print(f"{it + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     print(f"done: {cases} cases, {bad} mismatches")
+    from panda_amd import gpu_ffi as _ffi
+    _ffi.load().panda_ntt_set_streamed_tables(1)
     gm.deinit()
     sys.exit(1 if bad else 0)
 
