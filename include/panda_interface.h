@@ -200,10 +200,10 @@ panda_error panda_msm_plain_window_plan(unsigned curve, unsigned log_n, unsigned
 /* sorted entries per thread of the bucket-accumulation kernel, for experiments: 0 = built-in policy (rounded up to a multiple of 4) */
 panda_error panda_msm_set_chunk_entries(unsigned entries);
 /* With precomputed tables, levels 2 and 3 of the bucket sort for all but the first front_of_128 / 128 of the bucket space run on a second
- * stream of the calling host thread, beside the accumulation of that front part (which is launched as workgroups_per_cu workgroups per
- * CU so that the sort's workgroups find room next to it; 64 = the ordinary grid).  front_of_128: 1 .. 127, 0 = one stream, one phase
- * after the other, 0xffffffff = built-in policy (default: off -- measured slower on MI355X for BN254, profiles/r05_overlap_sort_accumulate.txt);
- * workgroups_per_cu: 0 = built-in (6 for BN254, three waves per SIMD), at most 64.  Same group element. */
+ * stream of the calling host thread, beside the accumulation of that front part; the rest is then accumulated on that second stream.
+ * workgroups_per_cu = 64: the front's accumulation is an ordinary grid; less: that many workgroups per CU whose waves draw their chunks
+ * from a counter; 0 = built-in (8 for BN254).  front_of_128: 1 .. 127, 0 = one stream, one phase after the other, 0xffffffff = built-in
+ * policy (default: off -- every schedule measured is slower on MI355X, profiles/r05_overlap_sort_accumulate.txt).  Same group element. */
 panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu);
 /* Experiments on the bucket-accumulation kernel of the 9-limb base fields (BN254): 0 = the built-in choice, 1 = five waves per SIMD with
  * the next entry's table row staged in LDS (global_load_lds) instead of registers, 2 = four waves per SIMD with the staged row. */
