@@ -1,0 +1,65 @@
+// ubench_gather_rate.hip -- how many random 64-byte rows per second the memory system of an MI355X delivers, by table size and by
+// resident waves per SIMD: the ceiling k_accumulate's row gathers (one per addition, 12 GiB of tables at 2^24 points) sit under.
+// build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/ubench_gather_rate tools/ubench_gather_rate.hip ; run: ./gpurun_out/ubench_gather_rate
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+template <int ILP>
+__global__ void __launch_bounds__(128) k_gather(const uint4 *__restrict__ table, uint64_t rows, unsigned iters, uint32_t *__restrict__ out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = t * 0x9E3779B97F4A7C15ull + 12345;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (unsigned i = 0; i < iters; i += ILP) {
+        uint4 v[ILP][4];
+#pragma unroll
+        for (int j = 0; j < ILP; j++) { // ILP independent rows in flight per lane
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            const uint4 *p = table + ((s >> 20) % rows) * 4;
+            v[j][0] = p[0]; v[j][1] = p[1]; v[j][2] = p[2]; v[j][3] = p[3];
+        }
+#pragma unroll
+        for (int j = 0; j < ILP; j++) {
+            acc.x ^= v[j][0].x ^ v[j][1].y ^ v[j][2].z ^ v[j][3].w;
+            acc.y += v[j][0].y + v[j][1].z + v[j][2].w + v[j][3].x;
+        }
+    }
+    out[t] = acc.x ^ acc.y;
+}
+
+int main()
+{
+    uint32_t *out;
+    uint4 *table;
+    const uint64_t max_rows = (12ull << 30) / 64;
+    hipMalloc(&table, max_rows * 64);
+    hipMalloc(&out, (1u << 22) * 4);
+    hipMemset(table, 1, max_rows * 64);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    printf("table_GiB,waves_per_simd,rows_in_flight_per_lane,G_rows_per_s,GB_per_s\n");
+    for (double gib : {0.125, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0})
+        for (unsigned waves : {4u})
+            for (int ilp : {1}) {
+                const uint64_t rows = (uint64_t)(gib * (1ull << 30)) / 64;
+                const unsigned threads = 256 * 4 * 64 * waves, iters = 256;
+                auto launch = [&] {
+                    if (ilp == 1)
+                        hipLaunchKernelGGL(k_gather<1>, dim3(threads / 128), dim3(128), 0, 0, table, rows, iters, out);
+                    else
+                        hipLaunchKernelGGL(k_gather<4>, dim3(threads / 128), dim3(128), 0, 0, table, rows, iters, out);
+                };
+                launch();
+                hipEventRecord(e0, 0);
+                for (int r = 0; r < 5; r++) launch();
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                const double rps = 5.0 * threads * iters / (ms * 1e-3);
+                printf("%.3f,%u,%d,%.2f,%.0f\n", gib, waves, ilp, rps / 1e9, rps * 64 / 1e9);
+            }
+    return 0;
+}
