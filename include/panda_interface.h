@@ -190,7 +190,8 @@ panda_error panda_msm_registered_info(const void *d_bases, unsigned *tables, uns
  * range's buckets are added into a running total on the device, which is reduced once.  Unregistered bases, or fewer than 2^16 points
  * in the first range, reduce the number of ranges, down to one copy followed by the ordinary call.  h_scalars == NULL skips the copies
  * and runs the same schedule on resident scalars.  Synchronous on return like panda_msm_execute_*; same group element.  curve: 0 .. 3
- * (BN254, BLS12-377, BLS12-381, BN254 G2). */
+ * (BN254, BLS12-377, BLS12-381, BN254 G2).  Experiment switch: ranges = 0x100 | R with h_scalars == NULL runs R (a power of two) EQUAL ranges
+ * one after the other on the caller's stream (the table-footprint measurement of profiles/r05_accumulate_table_footprint.txt). */
 panda_error panda_msm_execute_from_host(unsigned curve, const panda_msm_configuration exec_cfg, const void *h_scalars, unsigned ranges, panda_stream h2d_stream);
 
 /* Window size override for experiments: 0 = built-in policy (replaces get_window_bits_count, msm_cuda.cuh:21-45) */

@@ -871,16 +871,30 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     // 2^16 points, and only where the three-level sort has a geometry for the range sizes.  R ranges hold n/2^(R-1), n/2^(R-1),
     // n/2^(R-2), ..., n/2 points: the first upload -- the only one nothing runs beside -- is short, and every later range is at most
     // twice its predecessor, so its upload (PCIe moves a range about 1.9x faster than the kernels consume one) hides behind it.
-    unsigned nranges = (pipe && registered) ? std::min(std::max(pipe->ranges, 1u), 8u) : 1u;
+    // EQUAL ranges (pipe->ranges = 0x100 | R, R a power of two; resident scalars): R ranges of n / R points, one after the other on the
+    // caller's stream.  Not for uploads -- for the table footprint: a range gathers rows of W tables x n / R points, and the memory system
+    // serves random 64-byte rows 2.5x faster below ~3.5 GiB of footprint than above (profiles/r05_ubench_gather_rate.txt).
+    const bool equal_ranges = pipe && registered && (pipe->ranges & 0x100u) && !pipe->h_scalars;
+    unsigned eq_log = 0;
+    while (equal_ranges && (2u << eq_log) <= (pipe->ranges & 0xffu)) eq_log++;
+    unsigned nranges = equal_ranges ? (1u << eq_log) : ((pipe && registered) ? std::min(std::max(pipe->ranges & 0xffu, 1u), 8u) : 1u);
     auto ranges_ok = [&](unsigned R) {
+        if (equal_ranges) return log_n >= eq_log + 16 && (!tabled || panda::msm_sort_tabled_supported(log_n - eq_log, plan));
         if (log_n < (R - 1) + 16) return false;
         for (unsigned lc = log_n - (R - 1); tabled && lc < log_n; lc++)
             if (!panda::msm_sort_tabled_supported(lc, plan)) return false;
         return true;
     };
-    while (nranges > 1 && !ranges_ok(nranges)) nranges--;
-    auto range_log = [&](unsigned r) { return nranges == 1 ? log_n : log_n - (r == 0 ? nranges - 1 : nranges - r); };
-    auto range_row0 = [&](unsigned r) { return (nranges == 1 || r == 0) ? (u64)0 : (u64)1 << (log_n - (nranges - r)); };
+    if (equal_ranges) {
+        while (eq_log > 0 && !ranges_ok(1u << eq_log)) eq_log--;
+        nranges = 1u << eq_log;
+    } else
+        while (nranges > 1 && !ranges_ok(nranges)) nranges--;
+    auto range_log = [&](unsigned r) { return nranges == 1 ? log_n : (equal_ranges ? log_n - eq_log : log_n - (r == 0 ? nranges - 1 : nranges - r)); };
+    auto range_row0 = [&](unsigned r) {
+        if (equal_ranges) return (u64)r << (log_n - eq_log);
+        return (nranges == 1 || r == 0) ? (u64)0 : (u64)1 << (log_n - (nranges - r));
+    };
     struct RangeGeom {
         u64 stride;               // entries per list (upper bound)
         unsigned K, chunks, long_cap; // sorted entries per accumulate thread, accumulate threads per list, queue slots for long buckets
@@ -927,7 +941,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     // Ranges alternate between two lanes -- the caller's stream and a helper stream of this host thread -- each with its own sort
     // scratch, pieces and range buckets, so that range r+1 is sorted (LDS / HBM work) while range r is still being accumulated
     // (vector issue); the fix-ups, which all add into the one total, are chained by events.
-    const unsigned lanes = nranges > 1 ? 2u : 1u;
+    const unsigned lanes = (nranges > 1 && !equal_ranges) ? 2u : 1u; // equal ranges run one after the other: side by side they would share the footprint again
     PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + sz_l1 + sz_win + sz_slots + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);

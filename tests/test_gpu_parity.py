@@ -1689,6 +1689,32 @@ def test_msm_upload_pipeline_inside_one_call(gm, cid, k, tabled, chunks, source)
         d.free()
 
 
+@pytest.mark.parametrize("cid,k,R", [(0, 18, 4), (0, 19, 8), (1, 18, 2), (0, 17, 4)])
+def test_msm_equal_point_ranges_inside_one_call(gm, cid, k, R):
+    """panda_msm_execute_from_host with ranges = 0x100 | R and no host source: R equal point ranges one after the other on resident scalars
+    (the footprint experiment of profiles/r05_accumulate_table_footprint.txt); too small an input runs fewer ranges; same group element."""
+    lib = ffi.load()
+    n = 1 << k
+    lq = po.LC_Q[cid]
+    db, ds, dr = DeviceBuffer(n * 2 * lq * 4), DeviceBuffer(n * 32), DeviceBuffer(3 * lq * 4)
+    seed_b = 0xE90A1 + k
+    ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(cid, 0xE90A2 + k, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scalars = ds.to_host().reshape(n, 8)
+    ffi.check(lib.panda_msm_precompute_bases(cid, db.ptr, k, 0, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    try:
+        for _ in range(2):
+            ffi.check(lib.panda_memset(dr.ptr, 0, 3 * lq * 4), "memset")
+            ffi.check(lib.panda_msm_execute_from_host(cid, cfg, None, 0x100 | R, gm.exec_stream.raw), "msm in equal ranges")
+            assert (po.to_affine(cid, dr.to_host()) == po.expected_from_linearity(cid, seed_b, scalars)).all()
+    finally:
+        lib.panda_msm_unregister_bases(db.ptr)
+    assert (ds.to_host().reshape(n, 8) == scalars).all()
+    for d in (db, ds, dr):
+        d.free()
+
+
 def test_msm_upload_pipeline_through_the_manager(gm):
     """panda_msm_bn254_gpu_with_cached_bases over a registered base set takes the pipelined path (2^19 points: two ranges)."""
     k = 19

@@ -28,12 +28,16 @@ __global__ void __launch_bounds__(128) k_gather(const uint4 *__restrict__ table,
     out[t] = acc.x ^ acc.y;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     uint32_t *out;
     uint4 *table;
     const uint64_t max_rows = (12ull << 30) / 64;
-    hipMalloc(&table, max_rows * 64);
+    // argv[1] = 1: physically contiguous memory (hipExtMallocWithFlags, hipDeviceMallocContiguous): larger translation fragments
+    const bool contiguous = argc > 1 && argv[1][0] == '1';
+    hipError_t ae = contiguous ? hipExtMallocWithFlags((void **)&table, max_rows * 64, hipDeviceMallocContiguous) : hipMalloc(&table, max_rows * 64);
+    printf("allocation: %s -> %s\n", contiguous ? "hipDeviceMallocContiguous" : "hipMalloc", hipGetErrorName(ae));
+    if (ae != hipSuccess) return 1;
     hipMalloc(&out, (1u << 22) * 4);
     hipMemset(table, 1, max_rows * 64);
     hipEvent_t e0, e1;
