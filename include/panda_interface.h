@@ -207,7 +207,8 @@ panda_error panda_msm_set_chunk_entries(unsigned entries);
  * policy (default: off -- every schedule measured is slower on MI355X, profiles/r05_overlap_sort_accumulate.txt).  Same group element. */
 panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu);
 /* Experiments on the bucket-accumulation kernel of the 9-limb base fields (BN254): 0 = the built-in choice, 1 = five waves per SIMD with
- * the next entry's table row staged in LDS (global_load_lds) instead of registers, 2 = four waves per SIMD with the staged row. */
+ * the next entry's table row staged in LDS (global_load_lds) instead of registers, 2 = four waves per SIMD with the staged row, 3 = (every
+ * curve) the rows of a wave fetched four lanes to a row into LDS (profiles/r05_accumulate_table_footprint.txt).  Same group element. */
 panda_error panda_msm_set_accumulate_variant(unsigned variant);
 /* deprecated no-op kept so that code linked against the round-3 interface still loads (the bucket reduction has no groups any more) */
 panda_error panda_msm_set_reduce_group(unsigned log_group);

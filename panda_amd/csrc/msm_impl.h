@@ -58,7 +58,7 @@ struct MsmTuning {
     unsigned timing;       // 0: no device timers at all; 1: the call's total + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
     unsigned overlap_front; // with tables: size of the front part of the bucket space, in 1/128, whose accumulation runs beside the sort of the rest (0 = no overlap)
     unsigned overlap_wgs;   // workgroups per CU of that accumulation (6 = three waves per SIMD); 0 = the curve's default
-    unsigned acc_variant;   // experiments on k_accumulate (9-limb fields): 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it
+    unsigned acc_variant;   // experiments on k_accumulate: 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it (9-limb fields), 3 = rows fetched four lanes to a row (k_accumulate_shared)
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -292,6 +292,10 @@ __device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
     return lo;
 }
 
+// measurement builds only (-DPANDA_ROW_MASK=0x03ffffff: every gather confined to the first 4 GiB of rows; results are then wrong)
+#ifndef PANDA_ROW_MASK
+#define PANDA_ROW_MASK 0x7fffffffu
+#endif
 // a converted base as it sits in HBM: 2*L words, all zero for the identity
 template <class F>
 struct PackedBase {
@@ -301,7 +305,7 @@ struct PackedBase {
 template <class F>
 __device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
 {
-    load_words<2 * F::L>(b.w, bases + (u64)(entry & 0x7fffffffu) * 2 * F::L);
+    load_words<2 * F::L>(b.w, bases + (u64)(entry & PANDA_ROW_MASK) * 2 * F::L);
 }
 
 // RAW: a negated y comes back un-normalised (limbs < 2^31) -- good enough for the one product it feeds in
@@ -350,7 +354,7 @@ struct AccPart {
 template <class F>
 __device__ __forceinline__ void fetch_base_lds(uint4 *lds_wave, const u32 *bases, u32 entry)
 {
-    const u32 *src = bases + (u64)(entry & 0x7fffffffu) * 2 * F::L;
+    const u32 *src = bases + (u64)(entry & PANDA_ROW_MASK) * 2 * F::L;
 #pragma unroll
     for (int j = 0; j < 2 * F::L / 4; j++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * j), (__attribute__((address_space(3))) void *)(lds_wave + j * 64), 16, 0, 0);
@@ -527,6 +531,140 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
         // launch only took whole chunks)
         if (end > lo_pos || clamped) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
     }
+}
+
+// SHARED ROWS: the gathers of a wave, four lanes to a row.  A lane that loads its own 64-byte row issues four 16-byte loads that each
+// touch 64 different rows -- 64 different pages of a 12 GiB table --, and what then binds the gather rate is the number of address
+// translations per second, not HBM: 20 G rows/s beyond a footprint of ~4 GiB against 56 G rows/s below it, and 13 % of this kernel
+// (profiles/r05_accumulate_table_footprint.txt).  Here load instruction m of 2 L / 4 reads pieces 64 m .. 64 m + 63 of the wave's 64 rows
+// laid end to end -- piece f belongs to the row of lane f / P --, so one instruction touches 16 rows, and global_load_lds puts piece f at
+// 16 f bytes of the wave's LDS region: lane l finds its row at 64 l (tools/ubench_gather_rate.hip: 47.8 G rows/s at 12 GiB this way).
+// Every lane of the wave must take part in every fetch, so the loop runs a wave-uniform K iterations and a lane whose chunk is
+// shorter (the list's last wave) or absent offers row 0 and does nothing with it.
+template <class F>
+__device__ __forceinline__ void fetch_rows_shared(uint4 *lds_wave, const u32 *bases, u32 entry, unsigned lane)
+{
+    constexpr unsigned P = 2 * F::L / 4;
+#pragma unroll
+    for (unsigned m = 0; m < P; m++) {
+        const unsigned f = m * 64 + lane;
+        const u32 e = (u32)__shfl((int)entry, (int)(f / P));
+        const u32 *src = bases + (u64)(e & PANDA_ROW_MASK) * 2 * F::L + 4 * (f % P);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(lds_wave + m * 64), 16, 0, 0);
+    }
+}
+template <class F>
+__device__ __forceinline__ void read_row_shared(PackedBase<F> &b, const uint4 *lds_wave, unsigned lane)
+{
+    constexpr unsigned P = 2 * F::L / 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // see read_base_lds
+#pragma unroll
+    for (unsigned j = 0; j < P; j++) {
+        const uint4 v = lds_wave[lane * P + j];
+        b.w[4 * j] = v.x;
+        b.w[4 * j + 1] = v.y;
+        b.w[4 * j + 2] = v.z;
+        b.w[4 * j + 3] = v.w;
+    }
+}
+
+template <class F, int WAVES = (F::N <= 9 ? 4 : 2)>
+__global__ void __launch_bounds__(128, WAVES) k_accumulate_shared(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
+                                                           u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
+                                                           unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale)
+{
+    constexpr int PW = 4 * F::N;
+    constexpr unsigned P = 2 * F::L / 4;
+    const unsigned w = blockIdx.y;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) long_count[w] = 0;
+    if (stale && *stale) return;
+    const u32 *ow = off + (u64)w * (NB + 1);
+    const u32 *sw = sorted + (u64)w * stride;
+    u32 *bw = bucket_acc + (u64)w * NB * PW;
+    u32 *pw = parts + ((u64)w * chunks + t) * 2 * PW;
+    const u32 limit = ow[NB];
+    const bool has = t < chunks && (u64)t * K < limit;
+    if (__ballot(has) == 0) return; // wave-uniform
+    const u32 start = has ? t * K : 0u;
+    const u32 end = has ? (u32)min((u64)start + K, (u64)limit) : 0u;
+    __shared__ uint4 s_rows[2 * P * 64];
+    uint4 *lds_wave = s_rows + (threadIdx.x >> 6) * (P * 64);
+    const unsigned lane = threadIdx.x & 63u;
+
+    u32 b = 0, next = 0;
+    bool run_starts_inside = false;
+    if (has) {
+        b = owner_bucket(ow, NB, start);
+        next = ow[b + 1];
+        run_starts_inside = ow[b] >= start;
+    }
+    Xyzz<F> acc;
+    xyzz_set_identity(acc);
+    const bool quads = has && ((reinterpret_cast<uintptr_t>(sw + start) & 15) == 0);
+    uint4 quad = make_uint4(0, 0, 0, 0);
+    if (quads) quad = *reinterpret_cast<const uint4 *>(sw + start);
+    u32 cur_entry = has ? (quads ? quad.x : sw[start]) : 0u;
+    u32 ahead_entry = quads ? quad.y : (start + 1 < end ? sw[start + 1] : 0u);
+    fetch_rows_shared<F>(lds_wave, bases, cur_entry, lane);
+#pragma unroll 1
+    for (u32 i = 0; i < K; i++) { // K is the same for every lane: the fetches below are the whole wave's
+        const u32 pos = start + i;
+        const bool live = pos < end;
+        const u32 entry = cur_entry;
+        PackedBase<F> row;
+        read_row_shared<F>(row, lds_wave, lane);
+        Fe<F> cx, cy;
+        bool cinf;
+        unpack_base<F, ACC_RAW_Y && RawOperandOk<F>::value>(cx, cy, cinf, row, entry);
+        const bool boundary = live && pos >= next;
+        if (boundary) { // as in accumulate_chunk: the boundary's dependent loads come before the fetch is issued
+            store_xyzz<F>(run_starts_inside ? bw + (u64)b * PW : pw, acc);
+            run_starts_inside = true;
+            do {
+                b++;
+                next = ow[b + 1];
+            } while (next <= pos);
+            if (cinf)
+                xyzz_set_identity(acc);
+            else {
+                Fe<F> ty;
+                fe_norm(ty, cy);
+                xyzz_from_affine(acc, cx, ty);
+            }
+        }
+        cur_entry = (pos + 1 < end) ? ahead_entry : 0u;
+        if (i + 1 < K) fetch_rows_shared<F>(lds_wave, bases, cur_entry, lane);
+        if (pos + 2 < end) {
+            if (quads) {
+                const u32 idx = i + 2;
+                if ((idx & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(sw + pos + 2);
+                ahead_entry = (idx & 2u) ? ((idx & 1u) ? quad.w : quad.z) : ((idx & 1u) ? quad.y : quad.x);
+            } else
+                ahead_entry = sw[pos + 2];
+        }
+        if (!live || boundary || cinf) continue;
+        if (xyzz_is_identity(acc)) {
+            Fe<F> ty;
+            fe_norm(ty, cy);
+            xyzz_from_affine(acc, cx, ty);
+            continue;
+        }
+        const int rare = xyzz_madd_core(acc, cx, cy);
+        if (rare) {
+            if (rare == 1) {
+                PackedBase<F> again;
+                fetch_base<F>(again, bases, entry);
+                unpack_base<F>(cx, cy, cinf, again, entry);
+                xyzz_dbl_affine(acc, cx, cy);
+            } else
+                xyzz_set_identity(acc);
+        }
+    }
+    if (!has) return;
+    const bool ends_inside = next <= end;
+    u32 *dst = (run_starts_inside && ends_inside) ? bw + (u64)b * PW : (run_starts_inside ? pw + PW : pw);
+    store_xyzz<F>(dst, acc);
 }
 
 // bucket pieces: a bucket that spans chunks t0 < t1 is the LAST run of t0 (stored in slot 1, or slot 0 if it
@@ -1151,6 +1289,9 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // four waves per SIMD with the LDS-staged row
                 hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
                                    g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
+        } else if (tuning.acc_variant == 3) { // the wave's gathers four lanes to a row
+            hipLaunchKernelGGL((k_accumulate_shared<Fq>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
+                               g.K, g.chunks, d_lcount, registered ? d_stale : nullptr);
         } else
             hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
                                NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});

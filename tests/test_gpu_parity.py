@@ -1543,7 +1543,7 @@ def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, w
         d.free()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("k,wbits,kind", [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (13, 14, "all_equal"), (13, 14, "half_zero"), (13, 14, "small"), (13, 0, "plain")])
 def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
     """panda_msm_set_accumulate_variant: k_accumulate with the next entry's row staged in LDS (global_load_lds) at five / four waves per
@@ -1569,7 +1569,38 @@ def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
         lib.panda_msm_set_accumulate_variant(0)
         lib.panda_msm_unregister_bases(db.ptr)
     assert (got == po.msm_affine(0, bases, scalars, window_bits=11)).all()
-    assert lib.panda_msm_set_accumulate_variant(3) != 0
+    assert lib.panda_msm_set_accumulate_variant(4) != 0
+    for d in (db, ds, dr):
+        d.free()
+
+
+@pytest.mark.parametrize("cid,k,tables", [(1, 14, True), (2, 13, True), (3, 12, True), (1, 12, False), (3, 11, False), (0, 16, True)])
+def test_msm_accumulate_with_rows_fetched_four_lanes_to_a_row(gm, cid, k, tables):
+    """panda_msm_set_accumulate_variant(3) on every curve (rows of 64, 96 and 128 bytes: 4, 6, 8 pieces a row), tables and plain path"""
+    lib = ffi.load()
+    n = 1 << k
+    pt, res = ((64, 96), (96, 144), (96, 144), (128, 192))[cid]
+    fn = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381, lib.panda_msm_execute_bn254_g2)[cid]
+    db, ds, dr = DeviceBuffer(n * pt), DeviceBuffer(n * 32), DeviceBuffer(res)
+    seed_b = 0x5A4ED + k
+    ffi.check(lib.panda_gen_bases(cid, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(cid, 0x5A4EE + k, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scalars = ds.to_host().reshape(n, 8)
+    if tables:
+        ffi.check(lib.panda_msm_precompute_bases(cid, db.ptr, k, 0, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    try:
+        ffi.check(lib.panda_msm_set_accumulate_variant(3), "variant")
+        for _ in range(2):
+            ffi.check(lib.panda_memset(dr.ptr, 0, res), "memset")
+            ffi.check(fn(cfg), "msm")
+            if cid == 3:
+                assert _g2_decode(dr.to_host()) == _g2_expected(seed_b, scalars)
+            else:
+                assert (po.to_affine(cid, dr.to_host()) == po.expected_from_linearity(cid, seed_b, scalars)).all()
+    finally:
+        lib.panda_msm_set_accumulate_variant(0)
+        lib.panda_msm_unregister_bases(db.ptr)
     for d in (db, ds, dr):
         d.free()
 

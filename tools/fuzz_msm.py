@@ -47,7 +47,7 @@ def main():
         mode = int(rng.integers(0, 3))
         # the round-5 options ride along at random: the split sort (any cut, work-queue or plain grid) and the accumulate with its row in LDS
         ov = (int(rng.integers(1, 128)), int(rng.choice([0, 2, 6, 8, 64]))) if rng.random() < 0.5 else (0, 0)
-        variant = int(rng.integers(0, 3))
+        variant = int(rng.integers(0, 4))  # 3: rows fetched four lanes to a row (every curve)
         lib.panda_msm_set_overlap(*ov)
         lib.panda_msm_set_accumulate_variant(variant)
         if mode == 1:  # registered bases, plain windows: forced widths incl. the three-level sort with a list per window

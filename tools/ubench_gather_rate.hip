@@ -28,6 +28,38 @@ __global__ void __launch_bounds__(128) k_gather(const uint4 *__restrict__ table,
     out[t] = acc.x ^ acc.y;
 }
 
+// the same rows with four lanes per row: instruction m of 4 reads the rows of lanes 16m .. 16m+15, piece (lane & 3) each, so one
+// instruction touches 16 rows (16 pages) instead of 64; the pieces go through LDS back to the lane that owns the row.
+__global__ void __launch_bounds__(128) k_gather_coop(const uint4 *__restrict__ table, uint64_t rows, unsigned iters, uint32_t *__restrict__ out)
+{
+    __shared__ uint4 stage[128 * 4];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t s = t * 0x9E3779B97F4A7C15ull + 12345;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 *mine = stage + wave * 256;
+    for (unsigned i = 0; i < iters; i++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const uint64_t row = (s >> 20) % rows;
+        uint4 v[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const unsigned src = 16 * m + (lane >> 2);
+            const uint64_t r = ((uint64_t)__shfl((unsigned)(row >> 32), src) << 32) | __shfl((unsigned)row, src);
+            v[m] = table[r * 4 + (lane & 3)];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) mine[m * 64 + lane] = v[m]; // row of lane 16m + lane / 4, piece lane & 3: row-major
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        uint4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = mine[lane * 4 + j];
+        acc.x ^= w[0].x ^ w[1].y ^ w[2].z ^ w[3].w;
+        acc.y += w[0].y + w[1].z + w[2].w + w[3].x;
+    }
+    out[t] = acc.x ^ acc.y;
+}
+
 int main(int argc, char **argv)
 {
     uint32_t *out;
@@ -46,11 +78,13 @@ int main(int argc, char **argv)
     printf("table_GiB,waves_per_simd,rows_in_flight_per_lane,G_rows_per_s,GB_per_s\n");
     for (double gib : {0.125, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0})
         for (unsigned waves : {4u})
-            for (int ilp : {1}) {
+            for (int ilp : {1, 0}) { // 0: four lanes per row
                 const uint64_t rows = (uint64_t)(gib * (1ull << 30)) / 64;
                 const unsigned threads = 256 * 4 * 64 * waves, iters = 256;
                 auto launch = [&] {
-                    if (ilp == 1)
+                    if (ilp == 0)
+                        hipLaunchKernelGGL(k_gather_coop, dim3(threads / 128), dim3(128), 0, 0, table, rows, iters, out);
+                    else if (ilp == 1)
                         hipLaunchKernelGGL(k_gather<1>, dim3(threads / 128), dim3(128), 0, 0, table, rows, iters, out);
                     else
                         hipLaunchKernelGGL(k_gather<4>, dim3(threads / 128), dim3(128), 0, 0, table, rows, iters, out);
