@@ -12,6 +12,7 @@
 //                key is three digits deep: level 1 (per window), level 2 (per level-1 partition, ragged tiles),
 //                level 3 (one workgroup per (hi, mid) cell merges the W per-window runs and ranks the low bits).
 #include <algorithm>
+#include <cmath>
 
 #include "fe29.h"
 #include "msm_sort.h"
@@ -1006,13 +1007,35 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan, bool per_w
     g.W = plan.W;
     g.per_window = per_window ? 1u : 0u;
     g.b3 = std::min(std::min(7u, 31u - log_n), B);
-    // a level-3 cell (2^b3 buckets of all windows, or of one) should fit k3_merge's register-resident path: mean entries per cell
-    // = W n 2^b3 / 2^B (n 2^b3 / 2^B per window), kept below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars)
-    const u64 per_bucket_bits = per_window ? ((u64)1 << log_n) : ((u64)plan.W << log_n);
-    while (g.b3 > 3 && (per_bucket_bits >> (B - g.b3)) > (u64)K3_CAP * 4 / 5) g.b3--;
-    const unsigned rest = B - g.b3;
-    g.b1 = (rest + 1) / 2;
-    g.b2 = rest - g.b1;
+    // a level-3 cell (2^b3 buckets of all windows, or of one) should fit k3_merge's register-resident path.  The windows of a plan differ
+    // in width by up to a bit, and a window of c bits only reaches the lowest 2^(c-1) buckets: the cells at the bottom of the bucket
+    // space, which every window reaches, hold sum_k n 2^b3 / 2^(c_k - 1) entries -- 21.5 k at 2^24 points in 3 x 22 + 9 x 21 bits with
+    // b3 = 7, where the mean over all cells is 12.3 k: sized by the mean (rounds 3 and 4), the lower half of the cells took the slow path
+    // for oversized cells and k3_merge ran 1.00 ms instead of 0.50 (in-kernel stamps, profiles/r05_k3_merge_cells.txt).  Densest cell
+    // below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars).
+    double per_bucket = 0, mean_bucket = 0;
+    for (unsigned k = 0; k < plan.W; k++) {
+        const double d = ldexp((double)((u64)1 << log_n), -(int)(plan.width[k] - 1));
+        per_bucket = per_window ? std::max(per_bucket, d) : per_bucket + d;
+    }
+    mean_bucket = ldexp((double)(per_window ? (u64)1 << log_n : (u64)plan.W << log_n), -(int)B);
+    const unsigned b3_top = g.b3;
+    unsigned b3_mean = b3_top, b3_dense = b3_top;
+    while (b3_mean > 3 && ldexp(mean_bucket, (int)b3_mean) > (double)K3_CAP * 0.8) b3_mean--;
+    while (b3_dense > 3 && ldexp(per_bucket, (int)b3_dense) > (double)K3_CAP * 0.8) b3_dense--;
+    // sized by the densest cell the odd bit of the rest goes to level 2 (2^24: 128 x 256 partitions 1.385 ms, 256 x 128 1.43) -- unless
+    // level 1 would then need more than 256 partitions (2^26 points: 512 x 256 and 2^17 cells cost 1.0 ms more than the slow path of the
+    // lower cells does): then, and where both sizes agree, the geometry is the one sized by the mean
+    g.b3 = b3_dense;
+    unsigned rest = B - g.b3;
+    g.b2 = std::min((rest + 1) / 2, 8u);
+    g.b1 = rest - g.b2;
+    if (b3_dense == b3_mean || g.b1 > 8) {
+        g.b3 = b3_mean;
+        rest = B - g.b3;
+        g.b1 = (rest + 1) / 2;
+        g.b2 = rest - g.b1;
+    }
     g.H1 = 1u << g.b1;
     g.H2 = 1u << g.b2;
     g.S = g.W * g.H1;
