@@ -547,6 +547,13 @@ panda_error panda_msm_set_accumulate_variant(unsigned variant)
     return panda_success;
 }
 
+panda_error panda_msm_set_wide_merge(unsigned mode)
+{
+    if (mode > 2) return panda_error_invalid_value;
+    panda::msm_sort_set_wide_merge(mode);
+    return panda_success;
+}
+
 panda_error panda_msm_set_reduce_group(unsigned) { return panda_success; } // round-3 knob of a kernel that no longer exists
 
 panda_error panda_msm_set_chunk_entries(unsigned entries)

@@ -12,6 +12,7 @@
 //                key is three digits deep: level 1 (per window), level 2 (per level-1 partition, ragged tiles),
 //                level 3 (one workgroup per (hi, mid) cell merges the W per-window runs and ranks the low bits).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "fe29.h"
@@ -764,8 +765,13 @@ __global__ void __launch_bounds__(1024) k3_cell_offsets(const u32 *__restrict__ 
 
 constexpr unsigned K3_THREADS = 1024; // (512 threads on half-size cells, four workgroups per CU: k3_merge 0.994 -> 0.968 ms at 2^24, k1_scatter_split 0.535 -> 0.590 with its 256 partitions: round 5)
 constexpr unsigned K3_PER = 16;                     // words a thread keeps in registers
-constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once
+constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once; also the entries of the LDS image
+constexpr unsigned K3_PER_WIDE = 32;                // the variant for the dense half of the cells where the geometry cannot make them smaller
 
+// PER = K3_PER_WIDE: a cell of up to 2 K3_CAP entries is still read once -- 32 words and their ranks in registers (one workgroup per CU
+// instead of two) -- and leaves through the same LDS image in two rounds.  For the cells of the lower half of the bucket space at 2^25 and
+// 2^26 points, where the entry word leaves b3 only 5 or 6 bits and a smaller cell would make level 1 a 512-way partition.
+template <unsigned PER>
 __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
                                               const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
 {
@@ -827,26 +833,26 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel;
         return;
     }
-    if (N <= K3_CAP) {
+    if (N <= K3_THREADS * PER) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
         // (the cell's buckets are adjacent in the output)
         // ONE LDS atomic per entry: the count's return value is the entry's rank within its bucket, kept (with the bucket's 7 bits) in a
         // register until the offsets are known -- the ranking pass then needs no second atomic.  With 128 counters under 64 lanes the
         // atomics are the merge's bottleneck (two per entry: 1.00 ms at 2^24; one: see profiles/r04_msm_small_sizes.txt)
-        u32 word[K3_PER];
-        u32 where[K3_PER]; // run of the entry, then rank << 7 | bucket
+        u32 word[PER];
+        u32 where[PER]; // run of the entry, then rank << 7 | bucket, then its position in the cell
         unsigned k = 0;    // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
         // all of a thread's loads go out before the first word is looked at: with the count in the same loop every iteration waited
         // for its own HBM round trip (a dozen in sequence per workgroup)
 #pragma unroll
-        for (unsigned j = 0; j < K3_PER; j++) {
+        for (unsigned j = 0; j < PER; j++) {
             const u32 p = min(tid + j * K3_THREADS, N - 1); // positions past the end re-read the last entry and are dropped below (N > 0 here)
             while (p >= vstart[k + 1]) k++;
             where[j] = k;
             word[j] = p2[rbegin[k] + (p - vstart[k])];
         }
 #pragma unroll
-        for (unsigned j = 0; j < K3_PER; j++) {
+        for (unsigned j = 0; j < PER; j++) {
             const u32 p = tid + j * K3_THREADS;
             if (p < N) {
                 const u32 v = word[j];
@@ -866,12 +872,22 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel + N;
         __syncthreads();
 #pragma unroll
-        for (unsigned j = 0; j < K3_PER; j++) {
+        for (unsigned j = 0; j < PER; j++) {
             const u32 p = tid + j * K3_THREADS;
-            if (p < N) outbuf[cur[where[j] & 127u] + (where[j] >> 7)] = word[j];
+            if (p < N) where[j] = cur[where[j] & 127u] + (where[j] >> 7);
         }
-        __syncthreads();
-        for (u32 p = tid; p < N; p += K3_THREADS) sw[out_rel + p] = outbuf[p];
+#pragma unroll 1
+        for (u32 base = 0; base < N; base += K3_CAP) { // one round unless PER > K3_PER
+            if (base) __syncthreads(); // the image of the previous round has left
+#pragma unroll
+            for (unsigned j = 0; j < PER; j++) {
+                const u32 p = tid + j * K3_THREADS;
+                if (p < N && where[j] - base < K3_CAP) outbuf[where[j] - base] = word[j];
+            }
+            __syncthreads();
+            const u32 len = min(N - base, K3_CAP);
+            for (u32 p = tid; p < len; p += K3_THREADS) sw[out_rel + base + p] = outbuf[p];
+        }
         return;
     }
 
@@ -1007,35 +1023,18 @@ TabledGeom tabled_geom(unsigned log_n, const panda::WindowPlan &plan, bool per_w
     g.W = plan.W;
     g.per_window = per_window ? 1u : 0u;
     g.b3 = std::min(std::min(7u, 31u - log_n), B);
-    // a level-3 cell (2^b3 buckets of all windows, or of one) should fit k3_merge's register-resident path.  The windows of a plan differ
-    // in width by up to a bit, and a window of c bits only reaches the lowest 2^(c-1) buckets: the cells at the bottom of the bucket
-    // space, which every window reaches, hold sum_k n 2^b3 / 2^(c_k - 1) entries -- 21.5 k at 2^24 points in 3 x 22 + 9 x 21 bits with
-    // b3 = 7, where the mean over all cells is 12.3 k: sized by the mean (rounds 3 and 4), the lower half of the cells took the slow path
-    // for oversized cells and k3_merge ran 1.00 ms instead of 0.50 (in-kernel stamps, profiles/r05_k3_merge_cells.txt).  Densest cell
-    // below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars).
-    double per_bucket = 0, mean_bucket = 0;
-    for (unsigned k = 0; k < plan.W; k++) {
-        const double d = ldexp((double)((u64)1 << log_n), -(int)(plan.width[k] - 1));
-        per_bucket = per_window ? std::max(per_bucket, d) : per_bucket + d;
-    }
-    mean_bucket = ldexp((double)(per_window ? (u64)1 << log_n : (u64)plan.W << log_n), -(int)B);
-    const unsigned b3_top = g.b3;
-    unsigned b3_mean = b3_top, b3_dense = b3_top;
-    while (b3_mean > 3 && ldexp(mean_bucket, (int)b3_mean) > (double)K3_CAP * 0.8) b3_mean--;
-    while (b3_dense > 3 && ldexp(per_bucket, (int)b3_dense) > (double)K3_CAP * 0.8) b3_dense--;
-    // sized by the densest cell the odd bit of the rest goes to level 2 (2^24: 128 x 256 partitions 1.385 ms, 256 x 128 1.43) -- unless
-    // level 1 would then need more than 256 partitions (2^26 points: 512 x 256 and 2^17 cells cost 1.0 ms more than the slow path of the
-    // lower cells does): then, and where both sizes agree, the geometry is the one sized by the mean
-    g.b3 = b3_dense;
-    unsigned rest = B - g.b3;
-    g.b2 = std::min((rest + 1) / 2, 8u);
-    g.b1 = rest - g.b2;
-    if (b3_dense == b3_mean || g.b1 > 8) {
-        g.b3 = b3_mean;
-        rest = B - g.b3;
-        g.b1 = (rest + 1) / 2;
-        g.b2 = rest - g.b1;
-    }
+    // a level-3 cell (2^b3 buckets of all windows, or of one) should fit k3_merge's register-resident path: mean entries per cell
+    // = W n 2^b3 / 2^B (n 2^b3 / 2^B per window), kept below 0.8 K3_CAP (the counts are Poisson-tight for uniform scalars).
+    // The MEAN: the windows of a plan differ in width by up to a bit, and a window of c bits only reaches the lowest 2^(c-1) buckets, so
+    // the cells of the lower half of the bucket space hold up to twice the mean -- 21.5 k entries at 2^24 points in 3 x 22 + 9 x 21 bits,
+    // where the mean is 12.3 k.  Those cells are merged by the wide variant of k3_merge (sort3, wide_cells); until round 5 they took the
+    // slow path for oversized cells and the merge ran 1.00 ms instead of 0.55 (profiles/r05_k3_merge_cells.txt).  (Sizing the cells by the
+    // densest one instead -- b3 one less, 128 x 256 partitions -- costs levels 1 and 2 more than the wide variant costs level 3.)
+    const u64 per_bucket_bits = per_window ? ((u64)1 << log_n) : ((u64)plan.W << log_n);
+    while (g.b3 > 3 && (per_bucket_bits >> (B - g.b3)) > (u64)K3_CAP * 4 / 5) g.b3--;
+    const unsigned rest = B - g.b3;
+    g.b1 = (rest + 1) / 2;
+    g.b2 = rest - g.b1;
     g.H1 = 1u << g.b1;
     g.H2 = 1u << g.b2;
     g.S = g.W * g.H1;
@@ -1217,6 +1216,8 @@ static size_t sort3_bytes(unsigned log_n, const WindowPlan &plan, bool per_windo
            align256(lists * (NB + 1) * 4) + align256(E * 4) + 8192;
 }
 
+static std::atomic<unsigned> g_wide_merge{0};
+
 // the three-level sort: tabled mode (one list over all windows) or per-window mode (W lists)
 static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev, SortResult *out,
                         SortPlacement place, SampleCheck check, bool per_window, SortSplit *split)
@@ -1288,11 +1289,36 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     auto level3_counts = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_counts, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_suboff, d_cellcnt, d_blksum, g, R);
     };
+    // cells [0, wide_cells) hold more than the ordinary merge reads at once (and at most what the wide one does): in a plan of two widths the
+    // cells of the lower half of the bucket space, which every window reaches
+    unsigned wide_cells = 0;
+    if (!per_window) {
+        double per_bucket = 0;
+        unsigned narrow = plan.width[0];
+        for (unsigned k = 0; k < plan.W; k++) {
+            per_bucket += ldexp((double)n, -(int)(plan.width[k] - 1));
+            narrow = std::min(narrow, (unsigned)plan.width[k]);
+        }
+        const double densest = ldexp(per_bucket, (int)g.b3);
+        if (narrow + 1 == plan.width[0] && densest > (double)K3_CAP * 0.8 && densest <= (double)K3_THREADS * K3_PER_WIDE * 0.8) wide_cells = g.Q / 2;
+        const unsigned mode = g_wide_merge.load(std::memory_order_relaxed); // tests: every cell through the wide variant, or none
+        if (mode == 1) wide_cells = g.Q;
+        if (mode == 2) wide_cells = 0;
+    }
     auto level3_merge = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
-        if (s == stream)
-            hipLaunchKernelGGL(k3_merge, dim3(R.q_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
-        else // on the helper stream, beside the accumulation of the front: the variant that fits next to it
+        if (s == stream) {
+            // the dense half of the cells (tabled_geom) with the wide variant where they would not fit the ordinary one
+            const unsigned wide_hi = std::min(std::max(wide_cells, R.q_lo), R.q_hi);
+            if (wide_hi > R.q_lo) {
+                const SortRange Rw{R.s_lo, R.s_hi, R.q_lo, wide_hi};
+                hipLaunchKernelGGL(k3_merge<K3_PER_WIDE>, dim3(wide_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rw);
+            }
+            if (R.q_hi > wide_hi) {
+                const SortRange Rn{R.s_lo, R.s_hi, wide_hi, R.q_hi};
+                hipLaunchKernelGGL(k3_merge<K3_PER>, dim3(R.q_hi - wide_hi), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rn);
+            }
+        } else // on the helper stream, beside the accumulation of the front: the variant that fits next to it
             hipLaunchKernelGGL(k3_merge_small<256>, dim3(R.q_hi - R.q_lo), dim3(256), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);
     };
     // the cut between the front and the rest: a level-1 partition boundary whose first cell starts a block of 1024 cells
@@ -1339,6 +1365,7 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     return hipGetLastError();
 }
 
+void msm_sort_set_wide_merge(unsigned mode) { g_wide_merge.store(mode, std::memory_order_relaxed); }
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan) { return sort3_supported(log_n, plan, false); }
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan) { return sort3_bytes(log_n, plan, false); }
 

@@ -77,7 +77,7 @@ REFERENCE_SYMBOLS = [
 ]
 RUST_ONLY_SYMBOLS = ["panda_stream_synchronize", "panda_stream_query", "panda_device_enable_peer_access", "panda_device_disable_peer_access"]
 ADDITIVE_SYMBOLS = [
-    "panda_msm_register_bases", "panda_msm_unregister_bases", "panda_msm_execute_from_host", "panda_msm_precompute_bases", "panda_msm_registered_info", "panda_msm_set_chunk_entries", "panda_msm_set_overlap", "panda_msm_set_accumulate_variant", "panda_msm_set_reduce_group", "panda_msm_plain_window_plan", "panda_msm_verify_registered", "panda_msm_set_paranoid", "panda_msm_set_phase_timing", "panda_msm_setup_bls12_377", "panda_msm_execute_bls12_377", "panda_msm_execute_bls12_377_host", "panda_msm_set_window_bits",
+    "panda_msm_register_bases", "panda_msm_unregister_bases", "panda_msm_execute_from_host", "panda_msm_precompute_bases", "panda_msm_registered_info", "panda_msm_set_chunk_entries", "panda_msm_set_overlap", "panda_msm_set_accumulate_variant", "panda_msm_set_wide_merge", "panda_msm_set_reduce_group", "panda_msm_plain_window_plan", "panda_msm_verify_registered", "panda_msm_set_paranoid", "panda_msm_set_phase_timing", "panda_msm_setup_bls12_377", "panda_msm_execute_bls12_377", "panda_msm_execute_bls12_377_host", "panda_msm_set_window_bits",
     "panda_msm_last_phase_ms", "panda_msm_phase_name", "panda_ntt_last_device_ms", "panda_ntt_pass_plan", "panda_ntt_set_streamed_tables", "panda_ntt_execute_bn254_inverse", "panda_ntt_execute_bls12_377_v1", "panda_ntt_execute_bls12_377_inverse", "panda_msm_combine_bn254",
     "panda_msm_combine_bls12_377", "panda_msm_setup_bn254_g2", "panda_msm_execute_bn254_g2", "panda_msm_execute_bn254_g2_host", "panda_msm_combine_bn254_g2", "panda_msm_setup_bls12_381", "panda_msm_execute_bls12_381", "panda_msm_execute_bls12_381_host", "panda_msm_combine_bls12_381",
     "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_ntt_slab_inverse_step1_bn254_enqueue", "panda_ntt_slab_inverse_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
@@ -130,7 +130,7 @@ def load() -> C.CDLL:
         "panda_device_enable_peer_access": [C.c_int], "panda_device_disable_peer_access": [C.c_int],
         "panda_msm_execute_from_host": [u, MSMConfiguration, vp, u, PandaStream],
         "panda_msm_register_bases": [u, vp, u, PandaStream], "panda_msm_unregister_bases": [vp], "panda_msm_precompute_bases": [u, vp, u, u, PandaStream],
-        "panda_msm_registered_info": [vp, C.POINTER(u), C.POINTER(u), C.POINTER(sz)], "panda_msm_set_chunk_entries": [u], "panda_msm_set_overlap": [u, u], "panda_msm_set_accumulate_variant": [u], "panda_msm_set_reduce_group": [u], "panda_msm_plain_window_plan": [u, u, C.POINTER(u), C.POINTER(u)], "panda_msm_verify_registered": [vp, PandaStream], "panda_msm_set_paranoid": [u], "panda_msm_set_phase_timing": [u], "panda_msm_setup_bls12_377": [], "panda_msm_execute_bls12_377": [MSMConfiguration], "panda_msm_execute_bls12_377_host": [MSMConfiguration],
+        "panda_msm_registered_info": [vp, C.POINTER(u), C.POINTER(u), C.POINTER(sz)], "panda_msm_set_chunk_entries": [u], "panda_msm_set_overlap": [u, u], "panda_msm_set_accumulate_variant": [u], "panda_msm_set_wide_merge": [u], "panda_msm_set_reduce_group": [u], "panda_msm_plain_window_plan": [u, u, C.POINTER(u), C.POINTER(u)], "panda_msm_verify_registered": [vp, PandaStream], "panda_msm_set_paranoid": [u], "panda_msm_set_phase_timing": [u], "panda_msm_setup_bls12_377": [], "panda_msm_execute_bls12_377": [MSMConfiguration], "panda_msm_execute_bls12_377_host": [MSMConfiguration],
         "panda_msm_set_window_bits": [u], "panda_msm_last_phase_ms": [C.POINTER(C.c_float)], "panda_ntt_last_device_ms": [C.POINTER(C.c_float)], "panda_ntt_pass_plan": [u, C.POINTER(C.c_uint), C.POINTER(C.c_uint)], "panda_ntt_set_streamed_tables": [u], "panda_ntt_execute_bn254_inverse": [NttconfigurationV1], "panda_ntt_execute_bls12_377_v1": [NttconfigurationV1], "panda_ntt_execute_bls12_377_inverse": [NttconfigurationV1],
         "panda_msm_combine_bn254": [vp, u, C.c_int, vp], "panda_msm_combine_bls12_377": [vp, u, C.c_int, vp], "panda_msm_combine_bls12_381": [vp, u, C.c_int, vp],
         "panda_msm_setup_bn254_g2": [], "panda_msm_execute_bn254_g2": [MSMConfiguration], "panda_msm_execute_bn254_g2_host": [MSMConfiguration],

@@ -1081,7 +1081,7 @@ def test_cpp_gpu_manager_mirror():
         assert "manager_test: all ok" in r.stdout
 
 
-@pytest.mark.parametrize("cid,k,coord", [(0, 24, pgm.JACOBIAN), (1, 24, pgm.PROJECTIVE), (0, 26, pgm.JACOBIAN)])
+@pytest.mark.parametrize("cid,k,coord", [(0, 24, pgm.JACOBIAN), (1, 24, pgm.PROJECTIVE), (0, 25, pgm.JACOBIAN), (0, 26, pgm.JACOBIAN)])
 def test_msm_baseline_full_sizes(gm, cid, k, coord):
     """BASELINE.json's full sizes on one GPU: BN254 2^24 (the headline metric), BLS12-377 2^24 with Projective output
     (config 5) and BN254 2^26 (config 4's total).  No CPU MSM reaches these sizes; the size-independent check is the
@@ -1570,6 +1570,37 @@ def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
         lib.panda_msm_unregister_bases(db.ptr)
     assert (got == po.msm_affine(0, bases, scalars, window_bits=11)).all()
     assert lib.panda_msm_set_accumulate_variant(4) != 0
+    for d in (db, ds, dr):
+        d.free()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("k,wbits,kind", [(15, 14, "all_equal"), (16, 14, "all_equal"), (15, 0, "ones"), (14, 12, "small"), (16, 0, "half_zero"), (15, 16, "top_bit"), (17, 0, "uniform")])
+def test_msm_level3_merge_wide_variant(gm, mode, k, wbits, kind):
+    """panda_msm_set_wide_merge: every level-3 cell through the variant of k3_merge that reads up to 32 k entries per cell once and writes
+    them in two rounds (mode 1), or none (mode 2: large cells take the two-pass path).  2^15 equal scalars put exactly 32 k entries into
+    one cell (two rounds), 2^16 put 64 k (the two-pass path inside the wide kernel); the policy itself only picks the variant from 2^24 points
+    up (test_msm_baseline_full_sizes)."""
+    lib = ffi.load()
+    n = 1 << k
+    db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
+    seed_b = 0x51DE + k
+    ffi.check(lib.panda_gen_bases(0, seed_b, 0, n, db.ptr, NULL_STREAM), "gen")
+    scalars = po.gen_scalars(po.F_BN254_FR, 0x51DF + k, n) if kind == "uniform" else _edge_scalars(kind, n)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint32)
+    ffi.check(lib.panda_memcpy(ds.ptr, C.c_void_p(scalars.ctypes.data), n * 32), "memcpy")
+    ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, k, wbits, gm.exec_stream.raw), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    try:
+        ffi.check(lib.panda_msm_set_wide_merge(mode), "mode")
+        for _ in range(2):
+            ffi.check(lib.panda_memset(dr.ptr, 0, 96), "memset")
+            ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+            assert (po.to_affine(0, dr.to_host()) == po.expected_from_linearity(0, seed_b, scalars)).all()
+    finally:
+        lib.panda_msm_set_wide_merge(0)
+        lib.panda_msm_unregister_bases(db.ptr)
+    assert lib.panda_msm_set_wide_merge(3) != 0
     for d in (db, ds, dr):
         d.free()
 

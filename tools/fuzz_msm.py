@@ -50,6 +50,7 @@ def main():
         variant = int(rng.integers(0, 4))  # 3: rows fetched four lanes to a row (every curve)
         lib.panda_msm_set_overlap(*ov)
         lib.panda_msm_set_accumulate_variant(variant)
+        lib.panda_msm_set_wide_merge(int(rng.integers(0, 3)))  # level-3 merge: policy / every cell through the wide variant / none
         if mode == 1:  # registered bases, plain windows: forced widths incl. the three-level sort with a list per window
             lib.panda_msm_set_window_bits(int(rng.choice([0, 12, 16, 17, 19, 20])))
         wb = int(rng.choice([0, 0, 8, 10, 12, 14, 16, 18, 20, 22]))
@@ -77,6 +78,7 @@ def main():
             print(f"{it + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     lib.panda_msm_set_overlap(0xFFFFFFFF, 0)
     lib.panda_msm_set_accumulate_variant(0)
+    lib.panda_msm_set_wide_merge(0)
     print(f"done: {cases} cases, {bad} mismatches")
     gm.deinit()
     sys.exit(1 if bad else 0)
