@@ -768,6 +768,18 @@ constexpr unsigned K3_PER = 16;                     // words a thread keeps in r
 constexpr unsigned K3_CAP = K3_THREADS * K3_PER;    // a cell of up to this many entries is read from HBM once; also the entries of the LDS image
 constexpr unsigned K3_PER_WIDE = 32;                // the variant for the dense half of the cells where the geometry cannot make them smaller
 
+// measurement builds only (-DPANDA_K3_STAMPS, tools/k3_stamps.sh): s_memrealtime (100 MHz) at the phase boundaries of thread 0 of every 16th
+// workgroup of k3_merge, into a buffer nothing else reads -- how the overflowing lower cells were found (profiles/r05_k3_merge_cells.txt)
+#ifdef PANDA_K3_STAMPS
+__device__ unsigned long long g_k3_stamps[1024 * 8];
+#define K3_STAMP(n)                                                                                                          \
+    do {                                                                                                                     \
+        if (threadIdx.x == 0 && (cell & 15u) == 0 && (cell >> 4) < 1024) g_k3_stamps[(cell >> 4) * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define K3_STAMP(n)
+#endif
+
 // PER = K3_PER_WIDE: a cell of up to 2 K3_CAP entries is still read once -- 32 words and their ranks in registers (one workgroup per CU
 // instead of two) -- and leaves through the same LDS image in two rounds.  For the cells of the lower half of the bucket space at 2^25 and
 // 2^26 points, where the entry word leaves b3 only 5 or 6 bits and a smaller cell would make level 1 a 512-way partition.
@@ -787,6 +799,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     const unsigned nruns = g.per_window ? 1u : g.W;
     const unsigned h1 = q / g.H2, h2 = q % g.H2;
     const unsigned L = 1u << g.b3;
+    K3_STAMP(0);
     // position of the cell's first entry within its list, and where the list starts in `sorted` / `off`
     const u32 out_rel = cell_off[cell] - (g.per_window ? cell_off[k0 * g.Q] : 0u);
     // the last cell of a launch that stops short of the list's end also publishes where the NEXT cell's first bucket starts: the
@@ -812,6 +825,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         vstart[nruns] = run;
     }
     __syncthreads();
+    K3_STAMP(1); // setup: the runs of the cell, their prefix, two barriers
     const u32 N = vstart[nruns]; // uniform over the block
     const unsigned shift = g.log_n + 1;
     const u32 id_mask = (1u << g.log_n) - 1;
@@ -851,6 +865,11 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
             where[j] = k;
             word[j] = p2[rbegin[k] + (p - vstart[k])];
         }
+        K3_STAMP(2); // loads issued
+#ifdef PANDA_K3_STAMPS
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the wait for them on its own
+        K3_STAMP(3);
+#endif
 #pragma unroll
         for (unsigned j = 0; j < PER; j++) {
             const u32 p = tid + j * K3_THREADS;
@@ -861,7 +880,9 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
                 where[j] = (atomicAdd(&cnt[b], 1u) << 7) | b;
             }
         }
+        K3_STAMP(4); // LDS atomics
         __syncthreads();
+        K3_STAMP(5);
         u32 mine = tid < 128 ? cnt[tid] : 0;
         scan128_inclusive(cnt, &scan_carry);
         if (tid < L) {
@@ -888,6 +909,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
             const u32 len = min(N - base, K3_CAP);
             for (u32 p = tid; p < len; p += K3_THREADS) sw[out_rel + base + p] = outbuf[p];
         }
+        K3_STAMP(7); // scan, offsets, ranking into the LDS image, copy out
         return;
     }
 
@@ -916,6 +938,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         const u32 v = p2[rbegin[k] + (p - vstart[k])];
         sw[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
     }
+    K3_STAMP(6); // the two-pass path for oversized cells ends here (stamps 2 .. 5 and 7 stay zero)
 }
 
 // The same merge (tabled mode only) in at most 24 registers per thread: two passes over the cell's runs -- count, then rank into the LDS
@@ -1365,6 +1388,9 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     return hipGetLastError();
 }
 
+#ifdef PANDA_K3_STAMPS
+extern "C" int panda_debug_k3_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3_stamps), sizeof(unsigned long long) * 1024 * 8); }
+#endif
 void msm_sort_set_wide_merge(unsigned mode) { g_wide_merge.store(mode, std::memory_order_relaxed); }
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan) { return sort3_supported(log_n, plan, false); }
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan) { return sort3_bytes(log_n, plan, false); }
