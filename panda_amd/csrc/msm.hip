@@ -549,7 +549,7 @@ panda_error panda_msm_set_accumulate_variant(unsigned variant)
 
 panda_error panda_msm_set_wide_merge(unsigned mode)
 {
-    if (mode > 2) return panda_error_invalid_value;
+    if (mode > 3) return panda_error_invalid_value;
     panda::msm_sort_set_wide_merge(mode);
     return panda_success;
 }

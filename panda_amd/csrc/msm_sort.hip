@@ -780,15 +780,18 @@ __device__ unsigned long long g_k3_stamps[1024 * 8];
 #define K3_STAMP(n)
 #endif
 
+// THREADS = 256 (with PER = K3_PER: cells of up to 4096 entries): the sparse half of the cells -- 3 k entries each where the dense half
+// holds 21.5 k -- gave a 1024-thread workgroup three entries per thread; four-wave workgroups, eight to a CU, merge them in a fifth of the time.
 // PER = K3_PER_WIDE: a cell of up to 2 K3_CAP entries is still read once -- 32 words and their ranks in registers (one workgroup per CU
 // instead of two) -- and leaves through the same LDS image in two rounds.  For the cells of the lower half of the bucket space at 2^25 and
 // 2^26 points, where the entry word leaves b3 only 5 or 6 bits and a smaller cell would make level 1 a 512-way partition.
-template <unsigned PER>
-__global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
+template <unsigned PER, unsigned THREADS = K3_THREADS>
+__global__ void __launch_bounds__(THREADS) k3_merge(const u32 *__restrict__ p2, const u32 *__restrict__ part_off, const u32 *__restrict__ sub_off,
                                               const u32 *__restrict__ cell_off, u32 *__restrict__ off, u32 *__restrict__ sorted, TabledGeom g, unsigned NB, SortRange R)
 {
     __shared__ u32 cnt[128], cur[128], scan_carry;
-    __shared__ u32 outbuf[K3_CAP];
+    constexpr unsigned IMG = THREADS * K3_PER; // entries of the LDS image
+    __shared__ u32 outbuf[IMG];
     __shared__ u64 rbegin[64];
     __shared__ u32 rlen[64];
     __shared__ u32 vstart[65];
@@ -847,7 +850,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel;
         return;
     }
-    if (N <= K3_THREADS * PER) {
+    if (N <= THREADS * PER) {
         // one read: words stay in registers, are ranked into LDS in bucket order and leave as one linear, coalesced copy
         // (the cell's buckets are adjacent in the output)
         // ONE LDS atomic per entry: the count's return value is the entry's rank within its bucket, kept (with the bucket's 7 bits) in a
@@ -855,12 +858,12 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         // atomics are the merge's bottleneck (two per entry: 1.00 ms at 2^24; one: see profiles/r04_msm_small_sizes.txt)
         u32 word[PER];
         u32 where[PER]; // run of the entry, then rank << 7 | bucket, then its position in the cell
-        unsigned k = 0;    // a thread's positions grow by K3_THREADS, about one run: the run only ever steps forward
+        unsigned k = 0;    // a thread's positions grow by THREADS, about one run: the run only ever steps forward
         // all of a thread's loads go out before the first word is looked at: with the count in the same loop every iteration waited
         // for its own HBM round trip (a dozen in sequence per workgroup)
 #pragma unroll
         for (unsigned j = 0; j < PER; j++) {
-            const u32 p = min(tid + j * K3_THREADS, N - 1); // positions past the end re-read the last entry and are dropped below (N > 0 here)
+            const u32 p = min(tid + j * THREADS, N - 1); // positions past the end re-read the last entry and are dropped below (N > 0 here)
             while (p >= vstart[k + 1]) k++;
             where[j] = k;
             word[j] = p2[rbegin[k] + (p - vstart[k])];
@@ -872,7 +875,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
 #endif
 #pragma unroll
         for (unsigned j = 0; j < PER; j++) {
-            const u32 p = tid + j * K3_THREADS;
+            const u32 p = tid + j * THREADS;
             if (p < N) {
                 const u32 v = word[j];
                 word[j] = final_word(v, where[j]);
@@ -894,27 +897,27 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
         __syncthreads();
 #pragma unroll
         for (unsigned j = 0; j < PER; j++) {
-            const u32 p = tid + j * K3_THREADS;
+            const u32 p = tid + j * THREADS;
             if (p < N) where[j] = cur[where[j] & 127u] + (where[j] >> 7);
         }
 #pragma unroll 1
-        for (u32 base = 0; base < N; base += K3_CAP) { // one round unless PER > K3_PER
+        for (u32 base = 0; base < N; base += IMG) { // one round unless PER > K3_PER
             if (base) __syncthreads(); // the image of the previous round has left
 #pragma unroll
             for (unsigned j = 0; j < PER; j++) {
-                const u32 p = tid + j * K3_THREADS;
-                if (p < N && where[j] - base < K3_CAP) outbuf[where[j] - base] = word[j];
+                const u32 p = tid + j * THREADS;
+                if (p < N && where[j] - base < IMG) outbuf[where[j] - base] = word[j];
             }
             __syncthreads();
-            const u32 len = min(N - base, K3_CAP);
-            for (u32 p = tid; p < len; p += K3_THREADS) sw[out_rel + base + p] = outbuf[p];
+            const u32 len = min(N - base, IMG);
+            for (u32 p = tid; p < len; p += THREADS) sw[out_rel + base + p] = outbuf[p];
         }
         K3_STAMP(7); // scan, offsets, ranking into the LDS image, copy out
         return;
     }
 
     // oversized cell (heavily skewed scalars): count, then rank straight into global memory
-    for (u32 p = tid; p < N; p += K3_THREADS) {
+    for (u32 p = tid; p < N; p += THREADS) {
         const unsigned k = window_of(p);
         atomicAdd(&cnt[p2[rbegin[k] + (p - vstart[k])] >> shift], 1u);
     }
@@ -933,7 +936,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_merge(const u32 *__restrict__ p
     }
     if (q == g.Q - 1 && tid == 0) ow[NB] = out_rel + N;
     __syncthreads();
-    for (u32 p = tid; p < N; p += K3_THREADS) {
+    for (u32 p = tid; p < N; p += THREADS) {
         const unsigned k = window_of(p);
         const u32 v = p2[rbegin[k] + (p - vstart[k])];
         sw[atomicAdd(&cur[v >> shift], 1u)] = final_word(v, k);
@@ -1314,7 +1317,7 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
     };
     // cells [0, wide_cells) hold more than the ordinary merge reads at once (and at most what the wide one does): in a plan of two widths the
     // cells of the lower half of the bucket space, which every window reaches
-    unsigned wide_cells = 0;
+    unsigned wide_cells = 0, small_from = ~0u; // cells [small_from, Q): few enough entries for 256-thread workgroups
     if (!per_window) {
         double per_bucket = 0;
         unsigned narrow = plan.width[0];
@@ -1324,9 +1327,15 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
         }
         const double densest = ldexp(per_bucket, (int)g.b3);
         if (narrow + 1 == plan.width[0] && densest > (double)K3_CAP * 0.8 && densest <= (double)K3_THREADS * K3_PER_WIDE * 0.8) wide_cells = g.Q / 2;
+        // the other half of a two-width plan: only the wide windows reach it
+        double sparse_bucket = 0;
+        for (unsigned k = 0; k < plan.W; k++)
+            if (plan.width[k] == plan.width[0]) sparse_bucket += ldexp((double)n, -(int)(plan.width[k] - 1));
+        if (narrow + 1 == plan.width[0] && ldexp(sparse_bucket, (int)g.b3) <= 256.0 * K3_PER * 0.85) small_from = g.Q / 2;
         const unsigned mode = g_wide_merge.load(std::memory_order_relaxed); // tests: every cell through the wide variant, or none
-        if (mode == 1) wide_cells = g.Q;
-        if (mode == 2) wide_cells = 0;
+        if (mode == 1) wide_cells = g.Q, small_from = ~0u;
+        if (mode == 2) wide_cells = 0, small_from = ~0u;
+        if (mode == 3) wide_cells = 0, small_from = 0; // every cell through the 256-thread variant
     }
     auto level3_merge = [&](hipStream_t s, const SortRange &R) {
         hipLaunchKernelGGL(k3_cell_offsets, dim3((R.q_hi - R.q_lo + 1023) / 1024), dim3(s == stream ? 1024 : 256), 0, s, d_cellcnt, d_blksum, d_celloff, g, R);
@@ -1337,9 +1346,14 @@ static hipError_t sort3(hipStream_t stream, Arena &arena, unsigned fr, const voi
                 const SortRange Rw{R.s_lo, R.s_hi, R.q_lo, wide_hi};
                 hipLaunchKernelGGL(k3_merge<K3_PER_WIDE>, dim3(wide_hi - R.q_lo), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rw);
             }
-            if (R.q_hi > wide_hi) {
-                const SortRange Rn{R.s_lo, R.s_hi, wide_hi, R.q_hi};
-                hipLaunchKernelGGL(k3_merge<K3_PER>, dim3(R.q_hi - wide_hi), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rn);
+            const unsigned small_lo = std::min(std::max(small_from, wide_hi), R.q_hi);
+            if (small_lo > wide_hi) {
+                const SortRange Rn{R.s_lo, R.s_hi, wide_hi, small_lo};
+                hipLaunchKernelGGL(k3_merge<K3_PER>, dim3(small_lo - wide_hi), dim3(K3_THREADS), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rn);
+            }
+            if (R.q_hi > small_lo) {
+                const SortRange Rs{R.s_lo, R.s_hi, small_lo, R.q_hi};
+                hipLaunchKernelGGL((k3_merge<K3_PER, 256>), dim3(R.q_hi - small_lo), dim3(256), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, Rs);
             }
         } else // on the helper stream, beside the accumulation of the front: the variant that fits next to it
             hipLaunchKernelGGL(k3_merge_small<256>, dim3(R.q_hi - R.q_lo), dim3(256), 0, s, d_p2, d_poff, d_suboff, d_celloff, d_off, d_sorted, g, NB, R);

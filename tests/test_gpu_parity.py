@@ -1574,7 +1574,7 @@ def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
         d.free()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("k,wbits,kind", [(15, 14, "all_equal"), (16, 14, "all_equal"), (15, 0, "ones"), (14, 12, "small"), (16, 0, "half_zero"), (15, 16, "top_bit"), (17, 0, "uniform")])
 def test_msm_level3_merge_wide_variant(gm, mode, k, wbits, kind):
     """panda_msm_set_wide_merge: every level-3 cell through the variant of k3_merge that reads up to 32 k entries per cell once and writes
@@ -1600,7 +1600,7 @@ def test_msm_level3_merge_wide_variant(gm, mode, k, wbits, kind):
     finally:
         lib.panda_msm_set_wide_merge(0)
         lib.panda_msm_unregister_bases(db.ptr)
-    assert lib.panda_msm_set_wide_merge(3) != 0
+    assert lib.panda_msm_set_wide_merge(4) != 0
     for d in (db, ds, dr):
         d.free()
 

@@ -50,7 +50,7 @@ def main():
         variant = int(rng.integers(0, 4))  # 3: rows fetched four lanes to a row (every curve)
         lib.panda_msm_set_overlap(*ov)
         lib.panda_msm_set_accumulate_variant(variant)
-        lib.panda_msm_set_wide_merge(int(rng.integers(0, 3)))  # level-3 merge: policy / every cell through the wide variant / none
+        lib.panda_msm_set_wide_merge(int(rng.integers(0, 4)))  # level-3 merge: policy / every cell through the wide variant / none / every cell through the 256-thread one
         if mode == 1:  # registered bases, plain windows: forced widths incl. the three-level sort with a list per window
             lib.panda_msm_set_window_bits(int(rng.choice([0, 12, 16, 17, 19, 20])))
         wb = int(rng.choice([0, 0, 8, 10, 12, 14, 16, 18, 20, 22]))
