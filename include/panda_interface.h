@@ -211,8 +211,9 @@ panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per
  * curve) the rows of a wave fetched four lanes to a row into LDS (profiles/r05_accumulate_table_footprint.txt).  Same group element. */
 panda_error panda_msm_set_accumulate_variant(unsigned variant);
 /* Level-3 merge of the bucket sort (tabled calls): 0 = built-in (the cells of the lower half of the bucket space, which hold up to twice
- * the mean when the plan mixes two window widths, go through the variant that reads up to 32 k entries per cell once), 1 = every cell
- * through that variant, 2 = none (profiles/r05_k3_merge_cells.txt).  Same group element. */
+ * the mean when the plan mixes two window widths, go through the variant that reads up to 32 k entries per cell once, those of the upper
+ * half through 256-thread workgroups), 1 = every cell through the wide variant, 2 = neither variant, 3 = every cell through the 256-thread
+ * variant (profiles/r05_k3_merge_cells.txt).  Same group element. */
 panda_error panda_msm_set_wide_merge(unsigned mode);
 /* deprecated no-op kept so that code linked against the round-3 interface still loads (the bucket reduction has no groups any more) */
 panda_error panda_msm_set_reduce_group(unsigned log_group);

@@ -79,7 +79,8 @@ struct SortSplit {
 // every window falls into the same 2^(c-1) buckets and the window sums need no Horner step.
 bool msm_sort_tabled_supported(unsigned log_n, const WindowPlan &plan);
 // level-3 merge of the tabled sort: 0 = the wide variant (cells of up to 32 k entries read once) for the dense half of the cells where the
-// plan calls for it, 1 = for every cell, 2 = never (those cells then take the two-pass path)
+// plan calls for it and 256-thread workgroups for the sparse half, 1 = the wide variant for every cell, 2 = neither (large cells then take
+// the two-pass path), 3 = the 256-thread variant for every cell
 void msm_sort_set_wide_merge(unsigned mode);
 size_t msm_sort_tabled_bytes(unsigned log_n, const WindowPlan &plan);
 hipError_t msm_sort_tabled(hipStream_t stream, Arena &arena, unsigned fr, const void *scalars, unsigned log_n, const WindowPlan &plan, SortEvents ev,
