@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -416,9 +417,12 @@ panda_error panda_multi_gpu_create(panda_multi_gpu *out, const int *devices, uns
     if (!out || !devices || n_dev == 0 || n_dev > 64 || transport > PANDA_MULTI_LOOPBACK) return panda_error_invalid_value;
     int count = 0, caller_dev = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&caller_dev) != hipSuccess) return panda_error_invalid_value;
+    // Test-only knob: with PANDA_TEST_SHARED_DEVICE_RCCL set, several RCCL ranks may name one device.  Real RCCL refuses that itself; the knob
+    // exists for tests/fake_rccl (an LD_PRELOAD stand-in that validates and performs the RCCL calls of this file on a one-GPU box).
+    const bool one_rank_per_device = transport == PANDA_MULTI_RCCL && !getenv("PANDA_TEST_SHARED_DEVICE_RCCL");
     for (unsigned d = 0; d < n_dev; d++) {
         if (devices[d] < 0 || devices[d] >= count) return panda_error_invalid_value;
-        if (transport == PANDA_MULTI_RCCL)
+        if (one_rank_per_device)
             for (unsigned q = 0; q < d; q++)
                 if (devices[q] == devices[d]) return panda_error_invalid_value; // one RCCL rank per device
     }

@@ -225,11 +225,15 @@ int main(int argc, char **argv)
         REQUIRE(panda_get_device_number(&count) == 0 && count >= 1);
         unsigned g_rccl = 1;
         while (g_rccl * 2 <= (unsigned)count && g_rccl < 8) g_rccl *= 2;
+        // MANAGER_TEST_RCCL_RANKS_ON_DEVICE0=N (tests/test_fake_rccl.py, with tests/fake_rccl preloaded in place of RCCL and
+        // PANDA_TEST_SHARED_DEVICE_RCCL set): the RCCL pass runs N ranks on device 0 instead of one rank per device of the box
+        const unsigned shared_ranks = getenv("MANAGER_TEST_RCCL_RANKS_ON_DEVICE0") ? (unsigned)atoi(getenv("MANAGER_TEST_RCCL_RANKS_ON_DEVICE0")) : 0;
+        if (shared_ranks) g_rccl = shared_ranks;
         for (int pass = 0; pass < 2; pass++) {
             const unsigned G = pass == 0 ? g_rccl : 4;
             const unsigned transport = pass == 0 ? PANDA_MULTI_RCCL : PANDA_MULTI_LOOPBACK;
             std::vector<int> devices(G);
-            for (unsigned d = 0; d < G; d++) devices[d] = pass == 0 ? (int)d : 0;
+            for (unsigned d = 0; d < G; d++) devices[d] = pass == 0 && !shared_ranks ? (int)d : 0;
             panda_multi_gpu mg{};
             REQUIRE(panda_multi_gpu_create(&mg, devices.data(), G, transport) == 0);
             unsigned log_g = 0;
@@ -313,7 +317,8 @@ int main(int argc, char **argv)
     }
     { // the host-level wrapper a maintainer would write over those entry points: PandaMultiGpuManager (gpu_manager.hpp), from host slices
         PandaMultiGpuManager mgm;
-        REQUIRE(PandaMultiGpuManager::create({0, 0}, PANDA_MULTI_LOOPBACK, &mgm) == PandaGpuError::Ok);
+        const unsigned wrapper_transport = getenv("MANAGER_TEST_RCCL_RANKS_ON_DEVICE0") ? PANDA_MULTI_RCCL : PANDA_MULTI_LOOPBACK;
+        REQUIRE(PandaMultiGpuManager::create({0, 0}, wrapper_transport, &mgm) == PandaGpuError::Ok);
         const unsigned k = 15;
         const size_t n = (size_t)1 << k;
         std::vector<uint8_t> bases(n * 64), scalars(n * 32), whole, sharded;
@@ -332,7 +337,7 @@ int main(int argc, char **argv)
             if (tables == 0) { // re-stage with tables: drop the first registration
                 PandaMultiGpuManager again;
                 REQUIRE(mgm.deinit() == PandaGpuError::Ok);
-                REQUIRE(PandaMultiGpuManager::create({0, 0}, PANDA_MULTI_LOOPBACK, &again) == PandaGpuError::Ok);
+                REQUIRE(PandaMultiGpuManager::create({0, 0}, wrapper_transport, &again) == PandaGpuError::Ok);
                 mgm = again;
             }
         }
