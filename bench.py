@@ -505,7 +505,11 @@ def contract_line(full: dict) -> dict:
             line["cpu_baseline"]["value_16_threads"] = _sig(cb["multi_thread"]["value"])
     ri = full.get("roofline_issue")
     if ri:
-        line["roofline_issue"] = {k: _sig(ri[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "additions_per_launch", "mads_per_addition") if k in ri}
+        line["roofline_issue"] = {k: _sig(ri[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "additions_per_launch", "mads_per_addition",
+                                                           "k_accumulate_mcycles", "sclk_mhz") if k in ri}
+        if ri.get("sclk_mhz_by_xcd"):
+            line["roofline_issue"]["sclk_mhz_by_xcd"] = ri["sclk_mhz_by_xcd"]
+        line["k_accumulate_mcycles"] = _sig(ri.get("k_accumulate_mcycles"))
     if "phases_ms" in full:
         line["phases_ms"] = {k: _sig(v, 4) for k, v in full["phases_ms"].items()}
     vr = {f"2^{k}": _sig(_get(full, leg, "vs_reference_model", "value"), 3) for k, leg in ((20, "config2_msm_2_20"), (22, "msm_2_22")) if _get(full, leg, "vs_reference_model", "value")}
@@ -518,7 +522,7 @@ def contract_line(full: dict) -> dict:
         if isinstance(nt, dict) and "ms" in nt:
             line[name] = {"value": _sig(nt["value"]), "unit": "elements/s", "ms": _sig(nt["ms"], 4), "passes": nt.get("passes"), "radix_bits": nt.get("radix_bits"),
                           "roofline": {"bound": "hbm", "achieved": _sig(_get(nt, "roofline", "achieved")), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _sig(_get(nt, "roofline", "frac"), 4)},
-                          "issue_frac": _sig(_get(nt, "roofline_issue", "frac"), 4)}
+                          "issue_frac": _sig(_get(nt, "roofline_issue", "frac"), 4), "mcycles": _sig(nt.get("mcycles")), "sclk_mhz": _sig(nt.get("sclk_mhz"))}
     kms = {}
     for short, leg in (("c2", "config2_msm_2_20"), ("2_22", "msm_2_22"), ("c5", "config5_bls12_377_2_24_projective")):
         v = _get(full, leg, "with_tables", "k_accumulate_ms")
@@ -615,16 +619,23 @@ def main():
     log_n = args.log_n
     n = 1 << log_n
     prob = MsmProblem(ctx, 0, log_n, SEED, ctx.ffi.JACOBIAN, first=rank * n, register=not args.no_register, tables=not args.no_tables)
-    acc_ms = []
+    acc_ms, acc_clock = [], []
+    clk = (C.c_uint64 * ctx.ffi.CLOCK_WORDS)()
 
     def step(timed: bool):
         prob.execute()
         if timed:
             acc_ms.append(prob.phases())
+            lib.panda_msm_last_clock(clk)
+            acc_clock.append([int(v) for v in clk])
         prob.exchange()
 
     lib.panda_msm_set_phase_timing(1)  # the headline's roofline wants k_accumulate timed inside the timed steps (HIP events on its launch stream)
+    # ... and its CYCLES: marker kernels around the launch read s_memtime / s_memrealtime on every CU (panda_set_clock_stamps), so the
+    # record can tell a slower device (fewer MHz, same cycles) from a slower kernel (more cycles)
+    lib.panda_set_clock_stamps(1)
     dt = ctx.timed(step, args.warmup, args.steps)
+    lib.panda_set_clock_stamps(0)
     lib.panda_msm_set_phase_timing(0)
 
     out = None
@@ -634,6 +645,14 @@ def main():
         acc_kernel_ms = mean[3]  # HIP events around k_accumulate on its launch stream, inside the timed steps
         device_ms = mean[7]
         mean = prob.all_phases()  # every phase: separate untimed calls
+
+        # per timed step: [0] cycles of the slowest-clocked XCD (the one the launch waits for: the cycles the code needed), [1] 10 ns ticks,
+        # [2] XCDs stamped, [3] mean cycles over the XCDs (GRBM_GUI_ACTIVE / 8 of the same launch), [4..11] per XCD
+        stamped = [c for c in acc_clock if c[2] and c[1]]
+        acc_mcycles = sum(c[0] for c in stamped) / len(stamped) / 1e6 if stamped else None
+        acc_sclk_mhz = sum(c[3] / c[1] for c in stamped) / len(stamped) * 100.0 if stamped else None
+        acc_stamp_ms = sum(c[1] for c in stamped) / len(stamped) * 1e-5 if stamped else None
+        acc_xcd_mhz = [round(sum(c[4 + x] / c[1] for c in stamped) / len(stamped) * 100.0) for x in range(8)] if stamped else None
 
         achieved = BYTES_PER_POINT[0] * n / (acc_kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
@@ -669,7 +688,8 @@ def main():
                        "exchange": f"all-gather of 96 B partials ({'RCCL' if ctx.nccl else args.dist_backend}) + host point additions" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": BYTES_PER_POINT[0] * n, "kernel_ms": acc_kernel_ms},
+                         "algorithmic_bytes_per_launch": BYTES_PER_POINT[0] * n, "kernel_ms": acc_kernel_ms,
+                         "k_accumulate_mcycles": acc_mcycles, "sclk_mhz": acc_sclk_mhz},
             "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
             "device_ms_per_step": device_ms,
         }
@@ -687,6 +707,10 @@ def main():
             out["roofline_issue"] = {"bound": "valu issue (v_mad_u64_u32)", "kernel": "k_accumulate", "achieved": mads / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
                                      "unit": "T mad lane-ops/s", "frac": mads / MAD_PEAK_PER_S, "additions_per_launch": additions,
                                      "mads_per_addition": MADS_PER_ADDITION_BN254, "kernel_ms": acc_kernel_ms,
+                                     # clock-normalised: shader cycles of the launch (s_memtime around it, median over the 8 XCDs, mean over the timed steps)
+                                     # and the clock it ran at (cycles / s_memrealtime ticks x 100 MHz); cycles are the code's, MHz the box's
+                                     "k_accumulate_mcycles": acc_mcycles, "sclk_mhz": acc_sclk_mhz, "stamp_ms": acc_stamp_ms, "sclk_mhz_by_xcd": acc_xcd_mhz,
+                                     "mads_per_cycle_per_simd": (additions * MADS_PER_ADDITION_BN254 / 64.0 / (acc_mcycles * 1e6) / 1024.0) if acc_mcycles else None,
                                      "frac_of_bare_chain_rate": mads / MAD_BARE_CHAIN_PER_S,
                                      "valu_model": "4.7 cycles per multiply-add + 4 per other vector instruction on one vector pipe per SIMD reproduces the kernel's time "
                                                    "within 6 % (DESIGN.md section 7): the pipe is saturated, ~30 % of it by the masks, shifts and additions around the products",
@@ -948,19 +972,30 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int, field: int = 0) -> dict:
         while warm < 3 or time.perf_counter() - t_warm < 0.04:
             ffi.check(fn(cfg), "ntt")
             warm += 1
+        clk, cyc = (C.c_uint64 * ffi.CLOCK_WORDS)(), []
         for r in range(reps):
             t = time.perf_counter()
             ffi.check(fn(cfg), "ntt")
             w = time.perf_counter() - t
             ffi.check(lib.panda_ntt_last_device_ms(C.byref(ms)), "ntt_ms")
+            lib.panda_ntt_last_clock(clk)
+            if clk[1] and clk[2]:
+                cyc.append((int(clk[0]), int(clk[3]) / int(clk[1]) * 100.0))  # cycles of the slowest-clocked XCD; mean clock of the XCDs
             wall_ts.append(w)
             dev_ts.append(ms.value * 1e-3)
         dev_ts.sort()
         wall_ts.sort()
+        cyc.sort()
+        clock.append(cyc[len(cyc) // 2] if cyc else (None, None))
         return dev_ts[len(dev_ts) // 2], wall_ts[len(wall_ts) // 2]
 
-    fwd, fwd_wall = timed(lib.panda_ntt_execute_bls12_377_v1 if field else lib.panda_ntt_execute_bn254_v1)
-    inv, inv_wall = timed(lib.panda_ntt_execute_bls12_377_inverse if field else lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
+    clock = []  # per direction: (shader cycles of the passes, MHz), medians -- s_memtime / s_memrealtime markers around the passes (panda_set_clock_stamps)
+    lib.panda_set_clock_stamps(1)
+    try:
+        fwd, fwd_wall = timed(lib.panda_ntt_execute_bls12_377_v1 if field else lib.panda_ntt_execute_bn254_v1)
+        inv, inv_wall = timed(lib.panda_ntt_execute_bls12_377_inverse if field else lib.panda_ntt_execute_bn254_inverse)  # omega^-1 passes + fused n^-1
+    finally:
+        lib.panda_set_clock_stamps(0)
     gbs = BYTES_PER_NTT_ELEM * n / fwd / 1e9
     passes, bits = C.c_uint(0), (C.c_uint * 4)()
     ffi.check(lib.panda_ntt_pass_plan(log_n, C.byref(passes), bits), "ntt_plan")
@@ -969,6 +1004,7 @@ def ntt_one(ctx: Ctx, log_n: int, reps: int, field: int = 0) -> dict:
     return {"value": n / fwd, "unit": "elements/s", "ms": fwd * 1e3, "inverse_ms": inv * 1e3, "inverse_elements_per_s": n / inv,
             "forward_plus_inverse_ms": (fwd + inv) * 1e3, "forward_plus_inverse_elements_per_s": n / (fwd + inv),
             "wall_ms": fwd_wall * 1e3, "inverse_wall_ms": inv_wall * 1e3, "passes": passes.value, "radix_bits": [int(b) for b in bits if b],
+            "mcycles": clock[0][0] / 1e6 if clock[0][0] else None, "sclk_mhz": clock[0][1], "inverse_mcycles": clock[1][0] / 1e6 if clock[1][0] else None,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": BYTES_PER_NTT_ELEM * n}}
 

@@ -217,6 +217,9 @@ panda_error panda_msm_set_accumulate_variant(unsigned variant);
 panda_error panda_msm_set_wide_merge(unsigned mode);
 /* deprecated no-op kept so that code linked against the round-3 interface still loads (the bucket reduction has no groups any more) */
 panda_error panda_msm_set_reduce_group(unsigned log_group);
+/* 1 (built in): a small kernel behind the sort hands every chunk of the bucket-accumulation kernel the bucket its first entry falls in;
+ * 0: every thread of that kernel finds it by binary search over the bucket offsets, as rounds 1-5 did (A/B measurements). */
+panda_error panda_msm_set_chunk_first(unsigned on);
 /* Which device timers a call records (an event between two kernels keeps the GPU idle for about 6 us): 0 = none (default),
  * 1 = the call's total + the bucket-accumulation kernel, 2 = every phase.  Phases that were not timed read 0 in panda_msm_last_phase_ms. */
 panda_error panda_msm_set_phase_timing(unsigned level);
@@ -235,10 +238,33 @@ panda_error panda_ntt_last_device_ms(float *ms);
  * entries, zero-padded).  *flag of the execute calls is passes & 1.  The bit-reversed orderings run the same number of passes (radix-512
  * passes last for a bit-reversed input) except at 2^18 and 2^27, where they keep the eight-bit plan. */
 panda_error panda_ntt_pass_plan(unsigned log_n, unsigned *passes, unsigned *radix_bits);
-/* Streamed inter-pass table (experiment; 0 = off, the default): the second boundary of a three-pass transform (2^17 .. 2^24 points as
- * 8 + 8 + x bits) multiplies every element by ONE entry of a table over the whole twiddle index range -- 32 bytes per element of the
- * transform, built once per root and size, kept in the calling thread's twiddle cache -- instead of by two entries of 2^16-entry tables. */
-panda_error panda_ntt_set_streamed_tables(unsigned on);
+/* Streamed inter-pass table: the second boundary of a three-pass transform (2^17 .. 2^26 points) multiplies every element by ONE entry of
+ * a table over the whole twiddle index range -- 32 bytes per element of the transform, built once per root, size and direction, kept in
+ * the calling thread's twiddle cache (two slots) until panda_ntt_tear_down -- instead of by two entries of 2^16-entry tables.
+ *   mode 1 (the default policy): transforms of 2^17 .. 2^24 points; the table is as large as the data, at most 512 MiB per slot, so one host
+ *          thread that alternates forward and inverse 2^24-point transforms holds 1 GiB of tables (-6 % at 2^20, -4 % at 2^22, -1.4 % at 2^24)
+ *   mode 2: also 2^25 / 2^26 points (1 GiB / 2 GiB per slot, up to 4 GiB per thread; -1.7 % / -0.9 %) -- opt-in
+ *   mode 0: off (two small tables, as before round 5);  0xffffffff: back to the built-in policy;  3: test hook (allocation treated as failed)
+ * A table that does not fit in free HBM is skipped for that size and device from then on (per host thread); the call still succeeds. */
+panda_error panda_ntt_set_streamed_tables(unsigned mode);
+/* whole-transform twiddle-table sets built so far by the calling host thread: a repeated transform must not add to it (cache hit) */
+panda_error panda_ntt_table_builds(uint64_t *count);
+/* Clock stamps (measurement only; off by default).  With panda_set_clock_stamps(1) an MSM brackets the k_accumulate launch of its last
+ * range, and a whole NTT its passes, with a marker kernel in which one wave per CU stores s_memtime (shader cycles) and s_memrealtime
+ * (100 MHz); stamps are only compared within one CU (the cycle counter is not chip-wide).  panda_*_last_clock fills PANDA_CLOCK_WORDS u64:
+ *   [0] shader cycles of the XCD that showed the fewest -- the slowest-clocked one, which the launch waits for (the faster XCDs idle at
+ *       the end of a launch and show more): the cycles the CODE needed
+ *   [1] 10 ns ticks (median over the CUs)      [2] XCDs stamped on both sides      [3] mean of the XCDs' cycles: what rocprofv3's
+ *       GRBM_GUI_ACTIVE / 8 shows for the same launch; [3] / [1] x 100 MHz is the clock the BOX held     [4..11] cycles per XCD
+ * A record with cycles and MHz tells a slower kernel from a slower device.  panda_clock_stamp enqueues one marker on `stream` into a
+ * block of PANDA_CLOCK_STAMP_BYTES the device can write (clear it first); panda_clock_delta reduces two blocks (host copies) the same way. */
+#define PANDA_CLOCK_WORDS 12
+#define PANDA_CLOCK_STAMP_BYTES 32768
+panda_error panda_set_clock_stamps(unsigned on);
+panda_error panda_msm_last_clock(uint64_t *out /* PANDA_CLOCK_WORDS */);
+panda_error panda_ntt_last_clock(uint64_t *out /* PANDA_CLOCK_WORDS */);
+panda_error panda_clock_stamp(panda_stream stream, void *block /* PANDA_CLOCK_STAMP_BYTES */);
+panda_error panda_clock_delta(const void *before, const void *after, uint64_t *out /* PANDA_CLOCK_WORDS */);
 /* Bit-reversed orderings (SURVEY 8f-4 "bit-reversed NTT variants"): the forward transform with y[k] stored at bitrev(k), and the inverse
  * (n^-1 fused) of a buffer in that order back to natural-order coefficients.  Chaining them skips two permutations. */
 panda_error panda_ntt_execute_bn254_bitrev_out(const panda_ntt_configuration_v1 exec_cfg);

@@ -128,6 +128,96 @@ hipError_t thread_mailbox(uint32_t **host_words)
     return hipSuccess;
 }
 
+namespace {
+std::atomic<unsigned> g_clock_stamps{0};
+thread_local ClockDelta g_msm_clock, g_ntt_clock;
+
+__global__ void k_clock_stamp(ulonglong2 *block)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+        block[(xcc & 7u) * 256u + ((hw >> 8) & 255u)] = make_ulonglong2(t, r); // one 16-byte store: waves of one CU may race, any of them will do
+    }
+}
+
+struct StampBlocks {
+    uint64_t *words = nullptr;
+    void drop()
+    {
+        if (words) (void)hipHostFree(words);
+        words = nullptr;
+    }
+    ~StampBlocks() { drop(); }
+};
+thread_local StampBlocks g_stamp_blocks;
+} // namespace
+
+bool clock_stamps_enabled() { return g_clock_stamps.load(std::memory_order_relaxed) != 0; }
+void set_clock_stamps_enabled(bool on) { g_clock_stamps.store(on ? 1u : 0u, std::memory_order_relaxed); }
+
+hipError_t thread_stamp_blocks(uint64_t **host_blocks)
+{
+    if (!g_stamp_blocks.words) {
+        hipError_t e = hipHostMalloc((void **)&g_stamp_blocks.words, 4 * CLOCK_STAMP_SLOTS * 2 * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) {
+            g_stamp_blocks.words = nullptr;
+            return e;
+        }
+    }
+    *host_blocks = g_stamp_blocks.words;
+    return hipSuccess;
+}
+
+hipError_t enqueue_clock_stamp(hipStream_t s, uint64_t *block)
+{
+    hipLaunchKernelGGL(k_clock_stamp, dim3(2048), dim3(64), 0, s, (ulonglong2 *)block);
+    return hipGetLastError();
+}
+
+ClockDelta clock_delta(const uint64_t *before, const uint64_t *after)
+{
+    ClockDelta d;
+    std::vector<uint64_t> all_ticks;
+    uint64_t sum = 0;
+    for (unsigned x = 0; x < 8; x++) {
+        std::vector<uint64_t> cyc;
+        for (unsigned k = 0; k < 256; k++) {
+            const uint64_t *b = before + (size_t)(x * 256 + k) * 2, *a = after + (size_t)(x * 256 + k) * 2;
+            if (b[1] && a[1] > b[1] && a[0] > b[0]) {
+                cyc.push_back(a[0] - b[0]);
+                all_ticks.push_back(a[1] - b[1]);
+            }
+        }
+        if (cyc.empty()) continue;
+        std::sort(cyc.begin(), cyc.end());
+        d.per_xcd[x] = cyc[cyc.size() / 2];
+        sum += d.per_xcd[x];
+        d.xcds++;
+        if (!d.cycles || d.per_xcd[x] < d.cycles) d.cycles = d.per_xcd[x];
+    }
+    if (d.xcds) {
+        d.cycles_mean = sum / d.xcds;
+        std::sort(all_ticks.begin(), all_ticks.end());
+        d.ticks = all_ticks[all_ticks.size() / 2];
+    }
+    return d;
+}
+
+void clock_delta_out(const ClockDelta &d, uint64_t *out)
+{
+    out[0] = d.cycles;
+    out[1] = d.ticks;
+    out[2] = d.xcds;
+    out[3] = d.cycles_mean;
+    for (int x = 0; x < 8; x++) out[4 + x] = d.per_xcd[x];
+}
+
+ClockDelta &thread_msm_clock() { return g_msm_clock; }
+ClockDelta &thread_ntt_clock() { return g_ntt_clock; }
+
 hipError_t release_thread_arena()
 {
     g_helper.drop();
@@ -212,6 +302,7 @@ constexpr unsigned kOverlapAuto = 0xffffffffu;
 std::atomic<unsigned> g_overlap_front{kOverlapAuto};
 std::atomic<unsigned> g_overlap_wgs{0};
 std::atomic<unsigned> g_acc_variant{0};
+std::atomic<unsigned> g_chunk_first{1};
 
 // With tables, the accumulation of the first `front / 128` of the bucket space can run beside the sort of the rest (msm_impl.h,
 // "want_split").  Measured in round 5 and NOT the policy (profiles/r05_overlap_sort_accumulate.txt): k_accumulate<Bn254Fq> needs its
@@ -280,7 +371,7 @@ hipError_t msm_execute_on(unsigned curve, const panda_msm_configuration &cfg, co
 {
     const panda::MsmTuning tuning{pick_window_bits(panda::msm_scalar_field_of(curve), cfg.log_scalars_count), g_chunk.load(std::memory_order_relaxed),
                                   g_phase_timing.load(std::memory_order_relaxed), pick_overlap_front(cfg.log_scalars_count), g_overlap_wgs.load(std::memory_order_relaxed),
-                                  g_acc_variant.load(std::memory_order_relaxed)};
+                                  g_chunk_first.load(std::memory_order_relaxed), g_acc_variant.load(std::memory_order_relaxed)};
     switch (curve) {
     case 0: return panda::msm_execute_bn254(cfg, r, tuning, g_phase_ms, stale, pipe);
     case 1: return panda::msm_execute_bls377(cfg, r, tuning, g_phase_ms, stale, pipe);
@@ -547,6 +638,12 @@ panda_error panda_msm_set_accumulate_variant(unsigned variant)
     return panda_success;
 }
 
+panda_error panda_msm_set_chunk_first(unsigned on)
+{
+    g_chunk_first.store(on ? 1u : 0u, std::memory_order_relaxed);
+    return panda_success;
+}
+
 panda_error panda_msm_set_wide_merge(unsigned mode)
 {
     if (mode > 3) return panda_error_invalid_value;
@@ -574,6 +671,32 @@ panda_error panda_msm_last_phase_ms(float *ms)
 {
     if (!ms) return panda_error_invalid_value;
     for (int i = 0; i < PANDA_MSM_PHASES; i++) ms[i] = g_phase_ms[i];
+    return panda_success;
+}
+
+panda_error panda_set_clock_stamps(unsigned on)
+{
+    panda::set_clock_stamps_enabled(on != 0);
+    return panda_success;
+}
+
+panda_error panda_msm_last_clock(uint64_t *out)
+{
+    if (!out) return panda_error_invalid_value;
+    panda::clock_delta_out(panda::thread_msm_clock(), out);
+    return panda_success;
+}
+
+panda_error panda_clock_stamp(panda_stream stream, void *block)
+{
+    if (!block) return panda_error_invalid_value;
+    return static_cast<panda_error>(panda::enqueue_clock_stamp(static_cast<hipStream_t>(stream.handle), (uint64_t *)block));
+}
+
+panda_error panda_clock_delta(const void *before, const void *after, uint64_t *out)
+{
+    if (!before || !after || !out) return panda_error_invalid_value;
+    panda::clock_delta_out(panda::clock_delta((const uint64_t *)before, (const uint64_t *)after), out);
     return panda_success;
 }
 

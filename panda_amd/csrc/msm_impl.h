@@ -58,6 +58,7 @@ struct MsmTuning {
     unsigned timing;       // 0: no device timers at all; 1: the call's total + k_accumulate; 2: every phase (an event between two kernels costs ~6 us of idle GPU)
     unsigned overlap_front; // with tables: size of the front part of the bucket space, in 1/128, whose accumulation runs beside the sort of the rest (0 = no overlap)
     unsigned overlap_wgs;   // workgroups per CU of that accumulation (6 = three waves per SIMD); 0 = the curve's default
+    unsigned chunk_first;   // 1 (built in): k_chunk_first hands every chunk of k_accumulate its first bucket; 0: every thread searches the offsets for it (round 1-5)
     unsigned acc_variant;   // experiments on k_accumulate: 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it (9-limb fields), 3 = rows fetched four lanes to a row (k_accumulate_shared)
 };
 
@@ -292,6 +293,35 @@ __device__ __forceinline__ u32 owner_bucket(const u32 *off, u32 NB, u32 pos)
     return lo;
 }
 
+// The bucket that owns the first entry of every chunk, for all chunks at once: bucket b covers sorted positions [off[b], off[b + 1]) and
+// hands itself to the chunks that START there (t K in that range).  One coalesced pass over the offsets and chunks x 4 bytes written,
+// instead of a 21-step binary search over 8 MB of offsets in each of k_accumulate's 1.6 M threads (2^24 points: ~2 GB of the launch's
+// 16.2 GB of fetches and 21 dependent loads in front of every chunk).  A bucket long enough to start many chunks
+// (skewed scalars: all-equal puts n / K chunks into one bucket) is spread over the lanes of its wave.
+__global__ void __launch_bounds__(256) k_chunk_first(const u32 *__restrict__ off, u32 *__restrict__ first, unsigned NB, unsigned K, unsigned chunks)
+{
+    const unsigned w = blockIdx.y;
+    const u32 *ow = off + (u64)w * (NB + 1);
+    u32 *fw = first + (u64)w * chunks;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 t0 = 0, t1 = 0;
+    if (b < NB) {
+        const u32 lo = ow[b], hi = ow[b + 1];
+        t0 = (lo + K - 1) / K;
+        t1 = min((u32)((hi + K - 1) / K), (u32)chunks);
+    }
+    const unsigned lane = threadIdx.x & 63u;
+    u64 wide = __ballot(t1 > t0 + 4);
+    while (wide) {
+        const int src = __ffsll((long long)wide) - 1;
+        wide &= wide - 1;
+        const u32 a = (u32)__shfl((int)t0, src), e = (u32)__shfl((int)t1, src), owner = (u32)__shfl((int)b, src);
+        for (u32 t = a + lane; t < e; t += 64) fw[t] = owner;
+    }
+    if (t1 <= t0 + 4)
+        for (u32 t = t0; t < t1; t++) fw[t] = b;
+}
+
 // measurement builds only (-DPANDA_ROW_MASK=0x03ffffff: every gather confined to the first 4 GiB of rows; results are then wrong)
 #ifndef PANDA_ROW_MASK
 #define PANDA_ROW_MASK 0x7fffffffu
@@ -377,10 +407,9 @@ __device__ __forceinline__ void read_base_lds(PackedBase<F> &b, const uint4 *lds
 
 template <class F, bool LDSROW>
 __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, const u32 *__restrict__ sw, const u32 *__restrict__ ow, u32 *__restrict__ bw, u32 *__restrict__ pw,
-                                                 unsigned search_hi, u32 start, u32 end, uint4 *lds_wave, unsigned lane)
+                                                 u32 b, u32 start, u32 end, uint4 *lds_wave, unsigned lane)
 {
     constexpr int PW = 4 * F::N;
-    u32 b = owner_bucket(ow, search_hi, start);
     u32 next = ow[b + 1];
     bool run_starts_inside = ow[b] >= start; // only the first run of a chunk can have begun in an earlier chunk
     Xyzz<F> acc;
@@ -476,11 +505,15 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
 template <class F, bool PERSIST, int WAVES = (F::N <= 9 ? 4 : 2), bool LDSROW = false>
 __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
-                                                    unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale, AccPart part)
+                                                    unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale, AccPart part,
+                                                    const u32 *__restrict__ chunk_first)
 {
     constexpr int PW = 4 * F::N;
     const unsigned w = blockIdx.y;
     const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // the bucket a chunk starts in: handed over by k_chunk_first, or (launches on a part of the list whose offsets are still being
+    // written elsewhere: the experimental sort / accumulate overlap) found by binary search
+    const u32 *fw = chunk_first ? chunk_first + (u64)w * chunks : nullptr;
     if (t0 == 0) long_count[w] = 0; // the fix-up's queue of long buckets starts empty (it runs behind this kernel on the same stream)
     // the registered buffer no longer holds what was registered (the digits kernel of this range found out): the call will be repeated
     // from the caller's buffer, and nine tenths of the work it would waste are in this kernel
@@ -513,7 +546,8 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
                 end = limit;
                 clamped = true; // the list's last, short chunk: no earlier launch took it (they only take whole chunks), even if it ends AT lo_pos
             }
-            if (mine && (end > lo_pos || clamped)) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
+            if (mine && (end > lo_pos || clamped))
+                accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane);
         }
     } else {
         const unsigned t = t0;
@@ -529,7 +563,8 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
         }
         // (a short last chunk may end exactly at lo_pos -- everything lies in the earlier launch's part -- and still belongs here: the earlier
         // launch only took whole chunks)
-        if (end > lo_pos || clamped) accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, search_hi, start, end, lds_wave, lane);
+        if (end > lo_pos || clamped)
+            accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane);
     }
 }
 
@@ -1070,6 +1105,8 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         sz_parts = std::max(sz_parts, panda::align256((size_t)lists * g.chunks * 2 * PW * 4));
         sz_llist = std::max(sz_llist, panda::align256((size_t)lists * g.long_cap * 3 * 4));
     }
+    size_t sz_first = 0;
+    for (unsigned r = 0; r < nranges; r++) sz_first = std::max(sz_first, panda::align256((size_t)lists * range_geom(range_log(r)).chunks * 4));
     const size_t sz_bacc = panda::align256((size_t)lists * NB * PW * 4);
     const size_t sz_l1 = panda::align256((size_t)lists * (rc_rows + rc_cols * rc_csplit) * PW * 4);
     const size_t sz_win = 256; // the stale-registration flag (device copy: k_accumulate reads it)
@@ -1080,16 +1117,18 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
     // scratch, pieces and range buckets, so that range r+1 is sorted (LDS / HBM work) while range r is still being accumulated
     // (vector issue); the fix-ups, which all add into the one total, are chained by events.
     const unsigned lanes = (nranges > 1 && !equal_ranges) ? 2u : 1u; // equal ranges run one after the other: side by side they would share the footprint again
-    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + 1024) + sz_l1 + sz_win + sz_slots + 8192));
+    PANDA_TRY(arena.reserve(sz_bases + sz_bacc + lanes * (sz_sort + sz_bacc + sz_parts + sz_lcount + sz_llist + sz_first + 1280) + sz_l1 + sz_win + sz_slots + 8192));
     const u32 *d_bases = registered ? (const u32 *)registration->converted : (const u32 *)arena.take(sz_bases);
     u32 *d_bacc = (u32 *)arena.take(sz_bacc);
     u32 *d_bacc_range[2] = {d_bacc, d_bacc}, *d_parts_l[2] = {nullptr, nullptr}, *d_lcount_l[2] = {nullptr, nullptr}, *d_llist_l[2] = {nullptr, nullptr};
+    u32 *d_first_l[2] = {nullptr, nullptr};
     for (unsigned l = 0; l < lanes; l++) {
         if (nranges > 1) d_bacc_range[l] = (u32 *)arena.take(sz_bacc); // buckets of the range in flight on this lane, added into d_bacc by its fix-up
         d_parts_l[l] = (u32 *)arena.take(sz_parts);
         d_lcount_l[l] = (u32 *)arena.take(sz_lcount);
         d_llist_l[l] = (u32 *)arena.take(sz_llist);
-        if (!d_bacc_range[l] || !d_parts_l[l] || !d_lcount_l[l] || !d_llist_l[l]) return hipErrorOutOfMemory;
+        d_first_l[l] = (u32 *)arena.take(sz_first);
+        if (!d_bacc_range[l] || !d_parts_l[l] || !d_lcount_l[l] || !d_llist_l[l] || !d_first_l[l]) return hipErrorOutOfMemory;
     }
     u32 *d_l1 = (u32 *)arena.take(sz_l1);
     u32 *d_stale = (u32 *)arena.take(sz_win);
@@ -1117,6 +1156,14 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         else
             (void)hipGetLastError();
     }
+    // clock stamps around the accumulation of the last range (panda_set_clock_stamps; panda_internal.h)
+    const bool stamps = panda::clock_stamps_enabled();
+    uint64_t *stamp_block = nullptr;
+    if (stamps) {
+        PANDA_TRY(panda::thread_stamp_blocks(&stamp_block));
+        for (unsigned i = 0; i < 2 * 2 * panda::CLOCK_STAMP_SLOTS; i++) stamp_block[i] = 0;
+    }
+    panda::thread_msm_clock() = panda::ClockDelta{};
     const size_t sort_mark[2] = {arena.used, arena.used + panda::align256(sz_sort) + 512}; // a lane's sorts carve their scratch from its mark again
     hipStream_t lane_stream[2] = {stream, stream};
     if (lanes > 1) PANDA_TRY(panda::thread_helper_stream(&lane_stream[1]));
@@ -1240,10 +1287,18 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         if (sorted.lists != lists || sorted.NB != NB || sorted.stride != g.stride) return hipErrorInvalidValue;
         if (h_scalars && !last) PANDA_TRY(upload(r + 1)); // behind this range's sort in host order, beside its kernels on the device
         if (last && wanted(3)) PANDA_TRY(hipEventRecord(ev[3], ls));
+        if (last && stamps) PANDA_TRY(panda::enqueue_clock_stamp(ls, stamp_block));
         // the first range accumulates straight into the total (zeroed: empty buckets must read as the identity); a later range into
         // its lane's own array, of which only the non-empty buckets are ever read, by the fix-up that adds them to the total
         u32 *target = r == 0 ? d_bacc : d_bacc_range[lane];
         u32 *d_parts = d_parts_l[lane], *d_lcount = d_lcount_l[lane], *d_llist = d_llist_l[lane];
+        // every chunk's first bucket, for the launches that see the whole list (not for the split launches of the overlap experiment,
+        // whose later offsets are still being written when the front is accumulated)
+        const u32 *d_first = nullptr;
+        if (tuning.chunk_first && !split.active && tuning.acc_variant != 3) {
+            hipLaunchKernelGGL(k_chunk_first, dim3((NB + 255) / 256, lists), dim3(256), 0, ls, sorted.off, d_first_l[lane], NB, g.K, g.chunks);
+            d_first = d_first_l[lane];
+        }
         // (no zero-fill of the bucket array: the first range's fix-up writes the identity into its empty buckets; k_accumulate empties the
         // fix-up's queue of long buckets)
         if (split.active) {
@@ -1259,42 +1314,43 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
                 // built-in one (profiles/r05_accumulate_lds_row.txt), leave 96 registers per SIMD to the second stream's four-wave workgroups
                 if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
                     hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
-                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front, (const u32 *)nullptr);
                 else
                     hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3(all_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
-                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front, (const u32 *)nullptr);
             } else {
                 PANDA_TRY(hipMemsetAsync(d_queue, 0, 4, ls));
                 if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value)
                     // the kernel with its row staged in LDS, built for 96 registers: 8 workgroups per CU (4 waves per SIMD) leave 128 registers per
                     // SIMD and 96 KB of LDS to the sort's workgroups (of which only the four-wave ones are placed beside it: profiles/r05_overlap_*)
                     hipLaunchKernelGGL((k_accumulate<Fq, true, 5, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
-                                       g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                                       g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, front, (const u32 *)nullptr);
                 else
                     hipLaunchKernelGGL((k_accumulate<Fq, true>), dim3(persist_wgs, 1), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB, g.K,
-                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front);
+                                       g.chunks, d_lcount, registered ? d_stale : nullptr, front, (const u32 *)nullptr);
             }
             // the rest is accumulated on the HELPER stream, straight behind its sort: the two accumulate launches touch disjoint chunks, pieces and
             // buckets, so the second one's workgroups fill the CUs as the first one's last round drains (on one stream every launch boundary
             // costs about half a workgroup's lifetime -- 128 additions, 2.3 ms -- of a half-empty chip); the fix-up waits for both
             hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, 1), dim3(128), 0, split.helper, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
-                               g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB, nullptr});
+                               g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{split.pos, split.cut_cell, split.cells, 1u, NB, nullptr}, (const u32 *)nullptr);
             PANDA_TRY(hipEventRecord(split.rest_done, split.helper));
             PANDA_TRY(hipStreamWaitEvent(ls, split.rest_done, 0));
         } else if (Fq::N <= 9 && !IsExt2<Fq>::value && tuning.acc_variant == 1) {
             if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // five waves per SIMD, the next row staged in LDS (experiment: panda_msm_set_accumulate_variant)
                 hipLaunchKernelGGL((k_accumulate<Fq, false, 5, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
-                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
+                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr}, d_first);
         } else if (Fq::N <= 9 && !IsExt2<Fq>::value && tuning.acc_variant == 2) {
             if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // four waves per SIMD with the LDS-staged row
                 hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
-                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
+                                   g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr}, d_first);
         } else if (tuning.acc_variant == 3) { // the wave's gathers four lanes to a row
             hipLaunchKernelGGL((k_accumulate_shared<Fq>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
                                g.K, g.chunks, d_lcount, registered ? d_stale : nullptr);
         } else
             hipLaunchKernelGGL((k_accumulate<Fq, false>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride,
-                               NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr});
+                               NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr}, d_first);
+        if (last && stamps) PANDA_TRY(panda::enqueue_clock_stamp(ls, stamp_block + 2 * panda::CLOCK_STAMP_SLOTS));
         if (last && wanted(4)) PANDA_TRY(hipEventRecord(ev[4], ls));
         // 256-thread workgroups: at 2^16 buckets that is one per CU, a wave per SIMD (with 128 the dispatcher doubled them up on half
         // the CUs and every addition took 1.6x as long: fix-up 0.225 -> 0.162 ms at 2^20 points)
@@ -1356,6 +1412,7 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
         PANDA_TRY(hipStreamSynchronize(stream));
     }
 
+    if (stamps) panda::thread_msm_clock() = panda::clock_delta(stamp_block, stamp_block + 2 * panda::CLOCK_STAMP_SLOTS);
     float ms = 0;
     for (int i = 0; i < 6; i++) { // phases whose events were not recorded in this call read 0
         phase_ms[i] = 0;

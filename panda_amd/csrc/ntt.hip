@@ -482,22 +482,39 @@ PassPlan plan_passes(unsigned log_n, bool br_in = false, bool br_out = false)
 // (the twiddle's index range, 2^(log_p + 8 + deg2), exceeds the 2^16-entry tables: the second boundary of every three-pass transform),
 // it can read ONE 32-byte entry per element from a table over the whole range instead -- as large as the data, streamed beside it,
 // built once per root and size and cached -- and multiply once.
-std::atomic<unsigned> g_streamed_tables{1}; // the policy since round 5: -6 % at 2^20, -4 % at 2^22, -1.4 % at 2^24 (profiles/r05_ntt_streamed_table.txt)
+// Modes (panda_ntt_set_streamed_tables): 0 = off; 1 = the built-in policy: tables of up to 2^24 entries (512 MiB per direction and host
+// thread; -6 % at 2^20, -4 % at 2^22, -1.4 % at 2^24, profiles/r05_ntt_streamed_table.txt); 2 = also the 1 GiB / 2 GiB tables of 2^25 /
+// 2^26 points (-1.7 % / -0.9 %: not worth their memory by default); 3 = test hook: mode 1 with the table's allocation treated as failed
+// (the out-of-memory fallback below).
+constexpr unsigned STREAMED_POLICY = 1, STREAMED_LARGE = 2, STREAMED_FAIL_ALLOC = 3;
+constexpr unsigned STREAMED_POLICY_MAX_BITS = 24;
+std::atomic<unsigned> g_streamed_tables{STREAMED_POLICY};
 
 // log2 of the entries of the streamed table of pass j, 0 if that pass does not take one
-unsigned streamed_table_bits(const PassPlan &pl, unsigned j, unsigned log_n, bool allow)
+unsigned streamed_table_bits(const PassPlan &pl, unsigned j, unsigned log_n, unsigned mode)
 {
-    if (!allow || log_n < 11 || j + 1 >= pl.count || (pl.d[j] != 8 && pl.d[j] != 9)) return 0;
+    if (!mode || log_n < 11 || j + 1 >= pl.count || (pl.d[j] != 8 && pl.d[j] != 9)) return 0;
     unsigned log_p = 0;
     for (unsigned i = 0; i < j; i++) log_p += pl.d[i];
     const unsigned bits = log_p + pl.d[j] + pl.d[j + 1], cap = pl.wide ? 18u : 16u; // up to 2^cap entries the pass reads one table anyway
-    return (bits > cap && bits <= (unsigned)POW_BITS) ? bits : 0;
+    const unsigned most = mode == STREAMED_LARGE ? (unsigned)POW_BITS : STREAMED_POLICY_MAX_BITS;
+    return (bits > cap && bits <= most) ? bits : 0;
 }
+
+// A streamed table that did not fit once is not tried again by this host thread on that device (until panda_ntt_set_streamed_tables or
+// panda_ntt_tear_down): the transform runs with the two small tables under the key WITHOUT the streamed bit, so later calls hit the cache
+// instead of failing the large hipMalloc, dropping the other cache slot and rebuilding every table each time.
+struct StreamedUnavailable {
+    int device = -1;
+    unsigned bits = 0xffffffffu; // tables of at least 2^bits entries
+};
+thread_local StreamedUnavailable g_streamed_unavailable;
+thread_local uint64_t g_table_builds = 0; // whole-transform table sets built by this host thread (panda_ntt_table_builds)
 
 struct PassTables {
     size_t ta, tb, pq;
 };
-PassTables pass_tables(const PassPlan &pl, unsigned j, unsigned log_n = 0, bool streamed = false)
+PassTables pass_tables(const PassPlan &pl, unsigned j, unsigned log_n = 0, unsigned streamed = 0)
 {
     if (const unsigned bits = streamed_table_bits(pl, j, log_n, streamed)) return PassTables{panda::align256((size_t)32 << bits), 256, pl.wide ? SZ_PQ9 : SZ_PQ};
     if (!pl.wide) return PassTables{SZ_TA, SZ_TB, SZ_PQ};
@@ -505,7 +522,7 @@ PassTables pass_tables(const PassPlan &pl, unsigned j, unsigned log_n = 0, bool 
     return PassTables{last ? 256 : SZ_T18, last ? 256 : SZ_T18, SZ_PQ9};
 }
 // bytes ntt_passes carves out of its arena for a transform of 2^log_n points
-size_t passes_table_bytes(unsigned log_n, bool br_in = false, bool br_out = false, bool streamed = false)
+size_t passes_table_bytes(unsigned log_n, bool br_in = false, bool br_out = false, unsigned streamed = 0)
 {
     const PassPlan pl = plan_passes(log_n, br_in, br_out);
     size_t total = 0;
@@ -789,7 +806,7 @@ thread_local PassTimer g_pass_timer;
 // `build` = false reuses the tables already sitting in `arena` (same carve order).
 template <class Fr, class Alloc>
 hipError_t ntt_passes(hipStream_t stream, Alloc &arena, const u32 *src, u32 *dst, const Fe<Fr> &omega, unsigned log_n, const Fe<Fr> *scale,
-                      unsigned *passes_out, bool build = true, bool br_in = false, bool br_out = false, bool streamed = false)
+                      unsigned *passes_out, bool build = true, bool br_in = false, bool br_out = false, unsigned streamed = 0)
 {
     const u64 n = (u64)1 << log_n;
     unsigned log_p = 0, passes = 0;
@@ -932,10 +949,17 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (panda::extent_too_short(d_src, (size_t)32 << log_n) || panda::extent_too_short(d_dst, (size_t)32 << log_n)) return hipErrorInvalidValue;
     PANDA_TRY(order_after_null_stream(stream));
     u32 key[12];
-    bool streamed = g_streamed_tables.load(std::memory_order_relaxed) != 0;
-    twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u) | (streamed ? 8u : 0u), omega_wire); // the bit-reversed orderings may run another plan
     int dev = -1;
     PANDA_TRY(hipGetDevice(&dev));
+    const unsigned mode = g_streamed_tables.load(std::memory_order_relaxed);
+    unsigned streamed = mode == STREAMED_FAIL_ALLOC ? STREAMED_POLICY : mode, streamed_bits = 0;
+    {
+        const PassPlan pl = plan_passes(log_n, br_in, br_out);
+        for (unsigned j = 0; j < pl.count; j++) streamed_bits = std::max(streamed_bits, streamed_table_bits(pl, j, log_n, streamed));
+    }
+    if (!streamed_bits || (g_streamed_unavailable.device == dev && streamed_bits >= g_streamed_unavailable.bits)) streamed = 0;
+    const unsigned variant = (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u); // the bit-reversed orderings may run another plan
+    twiddle_key<Fr>(key, log_n, variant | (streamed << 3), omega_wire);
     // the entry that holds these tables, else the one that was not used last
     unsigned slot = g_whole_last ^ 1u;
     for (unsigned c = 0; c < 2; c++) {
@@ -952,26 +976,42 @@ hipError_t ntt_run(hipStream_t stream, void *d_src, void *d_dst, const u32 *omeg
     if (!hit) { // host-side parameters (two Fermat inversions for the inverse transform) only when tables are rebuilt
         fe_from_wire(omega, omega_wire);
         if (inverse) inverse_parameters<Fr>(omega, scale, (u64)1 << log_n);
-        hipError_t got = tw.ensure(passes_table_bytes(log_n, br_in, br_out, streamed) + 4096);
+        hipError_t got = (streamed && mode == STREAMED_FAIL_ALLOC) ? hipErrorOutOfMemory : tw.ensure(passes_table_bytes(log_n, br_in, br_out, streamed) + 4096);
         if (got == hipErrorOutOfMemory && streamed) {
-            // no room for a table as large as the data: the transform runs with the two small tables, as it did before round 5
+            // no room for a table as large as the data: the transform runs with the two small tables, as it did before round 5 -- and so do
+            // this thread's later transforms of this size and larger on this device (g_streamed_unavailable)
             (void)hipGetLastError();
-            streamed = false;
-            twiddle_key<Fr>(key, log_n, (inverse ? 1u : 0u) | (br_in ? 2u : 0u) | (br_out ? 4u : 0u), omega_wire);
-            got = tw.ensure(passes_table_bytes(log_n, br_in, br_out, false) + 4096);
+            if (g_streamed_unavailable.device != dev) g_streamed_unavailable = StreamedUnavailable{dev, streamed_bits};
+            g_streamed_unavailable.bits = std::min(g_streamed_unavailable.bits, streamed_bits);
+            streamed = 0;
+            twiddle_key<Fr>(key, log_n, variant, omega_wire);
+            got = tw.ensure(passes_table_bytes(log_n, br_in, br_out, 0) + 4096);
         }
         PANDA_TRY(got);
+        g_table_builds++;
     } else
         tw.used = 0;
     tw.valid = false;
     unsigned passes = 0;
     PassTimer &pt = g_pass_timer;
+    // clock stamps around the passes (panda_set_clock_stamps; panda_internal.h): cycles and the clock they ran at, beside the milliseconds
+    const bool stamps = panda::clock_stamps_enabled();
+    uint64_t *stamp_block = nullptr;
+    panda::thread_ntt_clock() = panda::ClockDelta{};
+    if (stamps) {
+        PANDA_TRY(panda::thread_stamp_blocks(&stamp_block));
+        stamp_block += 2 * 2 * panda::CLOCK_STAMP_SLOTS; // blocks 2 and 3 (0 and 1 are the MSM's)
+        for (unsigned i = 0; i < 2 * 2 * panda::CLOCK_STAMP_SLOTS; i++) stamp_block[i] = 0;
+    }
     PANDA_TRY(pt.begin(stream));
+    if (stamps) PANDA_TRY(panda::enqueue_clock_stamp(stream, stamp_block));
     PANDA_TRY(ntt_passes<Fr>(stream, tw, (const u32 *)d_src, (u32 *)d_dst, omega, log_n, inverse ? &scale : nullptr, &passes, !hit, br_in, br_out, streamed));
+    if (stamps) PANDA_TRY(panda::enqueue_clock_stamp(stream, stamp_block + 2 * panda::CLOCK_STAMP_SLOTS));
     PANDA_TRY(pt.end(stream));
     if (flag) *flag = passes & 1u;           // fft.cu:211
     PANDA_TRY(hipStreamSynchronize(stream)); // the reference is synchronous on return (fft.cu:202)
     pt.read();
+    if (stamps) panda::thread_ntt_clock() = panda::clock_delta(stamp_block, stamp_block + 2 * panda::CLOCK_STAMP_SLOTS);
     memcpy(tw.key, key, sizeof(key));
     tw.valid = true; // only after the tables are known to be complete
     tw.has_pending = false;
@@ -1385,6 +1425,13 @@ panda_error panda_ntt_slab_inverse_step2_bls12_381_enqueue(const panda_ntt_slab_
     return static_cast<panda_error>(slab_inverse_local<Bls381Fr>(cfg, false));
 }
 
+panda_error panda_ntt_last_clock(uint64_t *out)
+{
+    if (!out) return panda_error_invalid_value;
+    panda::clock_delta_out(panda::thread_ntt_clock(), out);
+    return panda_success;
+}
+
 panda_error panda_ntt_last_device_ms(float *ms)
 {
     if (!ms) return panda_error_invalid_value;
@@ -1392,9 +1439,19 @@ panda_error panda_ntt_last_device_ms(float *ms)
     return panda_success;
 }
 
-panda_error panda_ntt_set_streamed_tables(unsigned on)
+panda_error panda_ntt_set_streamed_tables(unsigned mode)
 {
-    g_streamed_tables.store(on ? 1u : 0u, std::memory_order_relaxed);
+    if (mode == 0xffffffffu) mode = STREAMED_POLICY; // "restore the built-in policy"
+    if (mode > STREAMED_FAIL_ALLOC) return panda_error_invalid_value;
+    g_streamed_tables.store(mode, std::memory_order_relaxed);
+    g_streamed_unavailable = StreamedUnavailable{}; // of the calling thread: a new setting gets a new try
+    return panda_success;
+}
+
+panda_error panda_ntt_table_builds(uint64_t *count)
+{
+    if (!count) return panda_error_invalid_value;
+    *count = g_table_builds;
     return panda_success;
 }
 
@@ -1412,6 +1469,7 @@ panda_error panda_ntt_tear_down(void)
 {
     std::lock_guard<std::mutex> lock(g_omega_mutex);
     g_omega_set = false;
+    g_streamed_unavailable = StreamedUnavailable{};
     for (auto &t : g_twiddles) (void)t.release();
     return static_cast<panda_error>(panda::release_thread_arena());
 }

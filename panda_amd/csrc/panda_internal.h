@@ -61,6 +61,33 @@ hipError_t thread_helper_stream(hipStream_t *out);
 constexpr size_t MAILBOX_WORDS = 16384;
 hipError_t thread_mailbox(uint32_t **host_words);
 
+// Clock stamps (measurement only, off unless panda_set_clock_stamps(1)): a marker kernel on the launch stream reads s_memtime (shader
+// cycles) and s_memrealtime (100 MHz) directly before and directly behind the kernel(s) of interest, so a run's record carries CYCLES and
+// the clock they ran at beside the milliseconds -- a slow device and a slower kernel read differently (cycles are the code's, MHz the
+// box's).  What the first version of this got wrong (profiles/r06_clock_stamps.txt): s_memtime is NOT one counter per XCD -- two waves of
+// one XCD on different shader engines read values ~10^8 apart -- so a stamp is only ever compared with a stamp taken on the SAME CU:
+// the marker runs 2048 one-wave workgroups (every CU gets several) and wave w stores {s_memtime, s_memrealtime} into the slot of its CU,
+// slot = XCC_ID * 256 + HW_ID[15:8] (shader engine, array, CU).  The XCDs hold different clocks (+-4 % on one device at one moment), and
+// the workgroups of a grid are dealt round the XCDs, so a kernel ends when the SLOWEST-clocked XCD is through: that XCD's cycle count is
+// the work, the others idle at the end and show more.  A stamp block is CLOCK_STAMP_SLOTS x 2 u64; blocks live in pinned host memory of
+// the calling thread (thread_stamp_blocks: four of them, MSM before / behind, NTT before / behind).
+constexpr unsigned CLOCK_STAMP_SLOTS = 2048;
+struct ClockDelta {
+    uint64_t cycles = 0;       // of the XCD with the fewest (the slowest clock: the one the kernel waits for); median over that XCD's CUs
+    uint64_t cycles_mean = 0;  // mean over the XCDs: what rocprofv3's GRBM_GUI_ACTIVE / 8 shows for the same launch
+    uint64_t ticks = 0;        // 10 ns, median over all paired CUs
+    unsigned xcds = 0;         // XCDs with at least one CU stamped on both sides
+    uint64_t per_xcd[8] = {};  // cycles of every XCD (0: none paired)
+};
+bool clock_stamps_enabled();
+void set_clock_stamps_enabled(bool on);
+hipError_t thread_stamp_blocks(uint64_t **host_blocks); // 4 blocks of CLOCK_STAMP_SLOTS x 2 u64, allocated on first use
+hipError_t enqueue_clock_stamp(hipStream_t s, uint64_t *block); // zeroes nothing: the host clears the block before the call
+ClockDelta clock_delta(const uint64_t *before, const uint64_t *after);
+ClockDelta &thread_msm_clock(); // of the last MSM / NTT of this host thread (zero when stamps are off)
+ClockDelta &thread_ntt_clock();
+void clock_delta_out(const ClockDelta &d, uint64_t *out); // the PANDA_CLOCK_WORDS u64 of panda_*_last_clock
+
 // drops every cached-bases registration whose buffer lies in the allocation `ptr` belongs to (msm.hip); called by
 // panda_free / panda_free_async before the memory goes back to the allocator
 void registry_forget_allocation(const void *ptr);

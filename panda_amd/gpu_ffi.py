@@ -58,6 +58,7 @@ class PandaMultiGpu(C.Structure):  # additive: include/panda_interface.h panda_m
 
 
 MULTI_RCCL, MULTI_LOOPBACK = 0, 1
+CLOCK_WORDS, CLOCK_STAMP_BYTES = 12, 32768  # PANDA_CLOCK_WORDS, PANDA_CLOCK_STAMP_BYTES
 
 
 class NttSlabConfiguration(C.Structure):  # additive: include/panda_interface.h panda_ntt_slab_configuration
@@ -82,6 +83,7 @@ ADDITIVE_SYMBOLS = [
     "panda_msm_combine_bls12_377", "panda_msm_setup_bn254_g2", "panda_msm_execute_bn254_g2", "panda_msm_execute_bn254_g2_host", "panda_msm_combine_bn254_g2", "panda_msm_setup_bls12_381", "panda_msm_execute_bls12_381", "panda_msm_execute_bls12_381_host", "panda_msm_combine_bls12_381",
     "panda_ntt_execute_bls12_381_v1", "panda_ntt_execute_bls12_381_inverse", "panda_ntt_execute_bn254_coset", "panda_ntt_execute_bn254_coset_inverse", "panda_ntt_execute_bn254_bitrev_out", "panda_ntt_execute_bn254_inverse_bitrev_in", "panda_ntt_slab_step1_bn254", "panda_ntt_slab_step2_bn254", "panda_ntt_slab_step1_bn254_enqueue", "panda_ntt_slab_step2_bn254_enqueue", "panda_ntt_slab_inverse_step1_bn254_enqueue", "panda_ntt_slab_inverse_step2_bn254_enqueue", "panda_gen_scalars", "panda_gen_bases",
     "panda_debug_field_op", "panda_debug_curve_op", "panda_version",
+    "panda_ntt_table_builds", "panda_msm_set_chunk_first", "panda_set_clock_stamps", "panda_msm_last_clock", "panda_ntt_last_clock", "panda_clock_stamp", "panda_clock_delta",
     "panda_multi_gpu_create", "panda_multi_gpu_destroy", "panda_multi_gpu_device_count", "panda_msm_execute_bn254_multi", "panda_msm_execute_bls12_377_multi",
     "panda_msm_execute_bn254_from_host_multi", "panda_msm_execute_bls12_377_from_host_multi",
     "panda_msm_execute_bls12_381_multi", "panda_msm_execute_bn254_g2_multi", "panda_msm_execute_bls12_381_from_host_multi", "panda_msm_execute_bn254_g2_from_host_multi",
@@ -144,6 +146,8 @@ def load() -> C.CDLL:
         "panda_ntt_slab_inverse_step1_bn254_enqueue": [NttSlabConfiguration], "panda_ntt_slab_inverse_step2_bn254_enqueue": [NttSlabConfiguration],
         "panda_gen_scalars": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream], "panda_gen_bases": [u, C.c_uint64, C.c_uint64, C.c_uint64, vp, PandaStream],
         "panda_debug_field_op": [u, u, vp, vp, vp, sz, PandaStream], "panda_debug_curve_op": [u, u, vp, vp, vp, sz, PandaStream],
+        "panda_ntt_table_builds": [C.POINTER(C.c_uint64)], "panda_msm_set_chunk_first": [u], "panda_set_clock_stamps": [u], "panda_msm_last_clock": [C.POINTER(C.c_uint64)],
+        "panda_ntt_last_clock": [C.POINTER(C.c_uint64)], "panda_clock_stamp": [PandaStream, vp], "panda_clock_delta": [vp, vp, C.POINTER(C.c_uint64)],
         "panda_multi_gpu_create": [C.POINTER(PandaMultiGpu), C.POINTER(C.c_int), u, u], "panda_multi_gpu_destroy": [PandaMultiGpu],
         "panda_multi_gpu_device_count": [PandaMultiGpu, C.POINTER(u)],
         "panda_msm_execute_bn254_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp], "panda_msm_execute_bls12_377_multi": [PandaMultiGpu, C.POINTER(MSMConfiguration), vp],

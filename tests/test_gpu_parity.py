@@ -24,6 +24,28 @@ def gm():
     m.deinit()
 
 
+@pytest.fixture(autouse=True)
+def _built_in_policies():
+    """Every test starts and ends on the library's built-in policies: the global knobs a test turns (window width, chunk size, overlap,
+    accumulate variant, merge mode, phase timers, streamed NTT tables, clock stamps) never leak into the tests that run after it, so the
+    shipped defaults are what the rest of the suite covers whatever the order."""
+    def reset():
+        lib = ffi.load()
+        lib.panda_msm_set_window_bits(0)
+        lib.panda_msm_set_chunk_entries(0)
+        lib.panda_msm_set_overlap(0xFFFFFFFF, 0)
+        lib.panda_msm_set_accumulate_variant(0)
+        lib.panda_msm_set_wide_merge(0)
+        lib.panda_msm_set_chunk_first(1)
+        lib.panda_msm_set_phase_timing(0)
+        lib.panda_msm_set_paranoid(0)
+        lib.panda_ntt_set_streamed_tables(0xFFFFFFFF)
+        lib.panda_set_clock_stamps(0)
+    reset()
+    yield
+    reset()
+
+
 def affine_of(cid, result_bytes, coord=pgm.JACOBIAN):
     w = np.asarray(result_bytes).view(np.uint32)
     return po.hom_to_affine(cid, w) if coord == pgm.PROJECTIVE else po.to_affine(cid, w)
@@ -478,7 +500,7 @@ def test_ntt_streamed_inter_pass_table(gm, cid, log_n):
     flag = C.c_uint(9)
     outs = []
     try:
-        for on in (0, 1, 0, 1):
+        for on in ((0, 2, 0, 2) if log_n > 24 else (0, 1, 0, 1)):  # 2^25 / 2^26: the 1 / 2 GiB tables are opt-in (mode 2)
             ffi.check(lib.panda_ntt_set_streamed_tables(on), "option")
             ffi.check(lib.panda_memcpy(d_a.ptr, C.c_void_p(x.ctypes.data), n * 32), "memcpy")
             cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(om.ctypes.data), log_n, C.pointer(flag))
@@ -491,7 +513,7 @@ def test_ntt_streamed_inter_pass_table(gm, cid, log_n):
             back = (o if flag.value else f).to_host().reshape(n, 8)
             assert np.array_equal(back, x), on
     finally:
-        lib.panda_ntt_set_streamed_tables(0)
+        lib.panda_ntt_set_streamed_tables(0xFFFFFFFF)  # the built-in policy (mode 1), not "off"
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     if log_n <= 20:
         assert np.array_equal(outs[1], po.ntt(fid, x, om, log_n))
@@ -501,6 +523,131 @@ def test_ntt_streamed_inter_pass_table(gm, cid, log_n):
             assert (outs[1][k] == po.ntt_eval_at(fid, x, om, log_n, k)).all(), k
     d_a.free()
     d_b.free()
+
+
+def test_ntt_streamed_table_policy_and_out_of_memory_fallback(gm):
+    """The default policy builds no streamed table beyond 2^24 entries (a 2^25-point transform under mode 1 and mode 0 builds the same
+    tables); and a streamed table that cannot be allocated (mode 3: the allocation is treated as failed) is given up ONCE: the call
+    succeeds with the two small tables, and the next calls hit the cache instead of rebuilding (the fallback used to store its
+    tables under a key the next call never looked up)."""
+    lib = ffi.load()
+    fid, log_n = po.F_BN254_FR, 19  # 8 + 8 + 3 bits: the middle pass takes a streamed table of 2^19 entries
+    n = 1 << log_n
+    om = po.root_of_unity(fid, log_n)
+    x = po.gen_scalars(fid, 0xFA11, n)
+    want = po.ntt(fid, x, om, log_n)
+    builds = C.c_uint64(0)
+
+    def count():
+        ffi.check(lib.panda_ntt_table_builds(C.byref(builds)), "builds")
+        return builds.value
+
+    def run():
+        buf = x.copy()
+        pgm.panda_ntt_bn254_gpu_v1(gm, buf, om, log_n)
+        assert (buf == want).all()
+
+    assert lib.panda_ntt_set_streamed_tables(4) == 1
+    ffi.check(lib.panda_ntt_set_streamed_tables(3), "option")
+    b0 = count()
+    run()
+    assert count() == b0 + 1  # built once, without the streamed table
+    run()
+    run()
+    assert count() == b0 + 1  # hits
+    pgm.panda_intt_bn254_gpu(gm, want.copy(), om, log_n)  # the other direction: the other cache slot, its own fallback, once
+    run()
+    assert count() == b0 + 2
+    ffi.check(lib.panda_ntt_set_streamed_tables(0xFFFFFFFF), "option")  # a new setting gets a new try: now the streamed table is built
+    run()
+    assert count() == b0 + 3
+    run()
+    assert count() == b0 + 3
+    # policy: 2^25 points under mode 1 use the same (non-streamed) tables as mode 0 -- no 1 GiB table by default
+    log_big = 25
+    d_a, d_b = DeviceBuffer(32 << log_big), DeviceBuffer(32 << log_big)
+    ffi.check(lib.panda_gen_scalars(0, 0xB16, 0, 1 << log_big, d_a.ptr, NULL_STREAM), "gen")
+    omb = po.root_of_unity(fid, log_big)
+    flag = C.c_uint(9)
+    free0, free1, total = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    cfg = ffi.NttconfigurationV1(gm.mem_pool, gm.exec_stream.raw, d_a.ptr, d_b.ptr, C.c_void_p(omb.ctypes.data), log_big, C.pointer(flag))
+    ffi.check(lib.panda_ntt_tear_down(), "tear_down")
+    ffi.check(lib.panda_mem_get_info(C.byref(free0), C.byref(total)), "mem_info")
+    ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
+    ffi.check(lib.panda_mem_get_info(C.byref(free1), C.byref(total)), "mem_info")
+    assert free0.value - free1.value < (256 << 20), "the default policy must not hold a table as large as a 2^25-point transform"
+    ffi.check(lib.panda_ntt_tear_down(), "tear_down")
+    d_a.free()
+    d_b.free()
+
+
+def test_clock_stamps_around_accumulate_and_ntt(gm):
+    """panda_set_clock_stamps: the marker kernels around k_accumulate (MSM) and around the passes (NTT) report shader cycles and 10 ns
+    ticks from all eight XCDs; cycles / ticks x 100 MHz is a plausible shader clock, the ticks agree with the HIP-event time of the same
+    launches, results are unchanged, and with the knob off nothing is stamped."""
+    lib = ffi.load()
+    k = 18
+    n = 1 << k
+    db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
+    ffi.check(lib.panda_gen_bases(0, 0xC10C, 0, n, db.ptr, NULL_STREAM), "gen")
+    ffi.check(lib.panda_gen_scalars(0, 0xC10D, 0, n, ds.ptr, NULL_STREAM), "gen")
+    scratch = DeviceBuffer(32 << 22)
+    ffi.check(lib.panda_msm_precompute_bases(0, db.ptr, k, 0, NULL_STREAM), "precompute")
+    cfg = ffi.MSMConfiguration(gm.mem_pool, gm.exec_stream.raw, db.ptr, ds.ptr, dr.ptr, k, pgm.JACOBIAN)
+    out, ph = (C.c_uint64 * ffi.CLOCK_WORDS)(), (C.c_float * 8)()
+    try:
+        ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        plain = dr.to_host()
+        ffi.check(lib.panda_msm_last_clock(out), "clock")
+        assert list(out) == [0] * ffi.CLOCK_WORDS
+        ffi.check(lib.panda_set_clock_stamps(1), "stamps")
+        ffi.check(lib.panda_msm_set_phase_timing(1), "timing")
+        for _ in range(3):
+            ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        assert (affine_of(0, dr.to_host()) == affine_of(0, plain)).all()  # (the Jacobian triple itself differs from run to run)
+        ffi.check(lib.panda_msm_last_clock(out), "clock")
+        ffi.check(lib.panda_msm_last_phase_ms(ph), "phases")
+        cycles, ticks, xcds, mean = out[0], out[1], out[2], out[3]
+        assert xcds == 8 and cycles > 0 and ticks > 0
+        per = list(out[4:12])
+        assert min(per) == cycles and cycles <= mean <= max(per) and max(per) < 1.2 * cycles, per  # the XCDs' clocks differ by a few per cent, not more
+        mhz = mean / ticks * 100.0
+        assert 900.0 < mhz < 2700.0, mhz
+        assert abs(ticks * 1e-5 - ph[3]) < 0.05 + 0.1 * ph[3], (ticks * 1e-5, ph[3])  # 10 ns ticks vs the events around the same launch
+        # NTT
+        log_n = 20
+        om = po.root_of_unity(po.F_BN254_FR, log_n)
+        x = po.gen_scalars(po.F_BN254_FR, 0xC10E, 1 << log_n)
+        buf = x.copy()
+        pgm.panda_ntt_bn254_gpu_v1(gm, buf, om, log_n)
+        buf = x.copy()
+        pgm.panda_ntt_bn254_gpu_v1(gm, buf, om, log_n)
+        assert (buf == po.ntt(po.F_BN254_FR, x, om, log_n)).all()
+        ms = C.c_float(0)
+        ffi.check(lib.panda_ntt_last_clock(out), "clock")
+        ffi.check(lib.panda_ntt_last_device_ms(C.byref(ms)), "ms")
+        assert out[2] == 8 and 900.0 < out[3] / out[1] * 100.0 < 2700.0 and max(out[4:12]) < 1.2 * out[0]
+        assert abs(out[1] * 1e-5 - ms.value) < 0.05 + 0.1 * ms.value
+        # the generic marker: two stamps on a stream with a known amount of work between them
+        sb = ffi.CLOCK_STAMP_BYTES
+        blocks = DeviceBuffer(2 * sb)
+        ffi.check(lib.panda_memset(blocks.ptr, 0, 2 * sb), "memset")
+        ffi.check(lib.panda_clock_stamp(gm.exec_stream.raw, blocks.ptr), "stamp")
+        ffi.check(lib.panda_gen_scalars(0, 1, 0, 1 << 22, scratch.ptr, gm.exec_stream.raw), "work")
+        ffi.check(lib.panda_clock_stamp(gm.exec_stream.raw, C.c_void_p(blocks.ptr.value + sb)), "stamp")
+        ffi.check(lib.panda_stream_sync(gm.exec_stream.raw), "sync")
+        host = blocks.to_host(np.uint64)
+        ffi.check(lib.panda_clock_delta(C.c_void_p(host.ctypes.data), C.c_void_p(host.ctypes.data + sb), out), "delta")
+        assert out[2] == 8 and out[0] > 0 and 900.0 < out[3] / out[1] * 100.0 < 2700.0
+        ffi.check(lib.panda_set_clock_stamps(0), "stamps")
+        ffi.check(lib.panda_msm_execute_bn254(cfg), "msm")
+        ffi.check(lib.panda_msm_last_clock(out), "clock")
+        assert list(out) == [0] * ffi.CLOCK_WORDS
+        blocks.free()
+    finally:
+        lib.panda_msm_unregister_bases(db.ptr)
+        for d in (db, ds, dr, scratch):
+            d.free()
 
 
 def test_ntt_setup_then_execute(gm):

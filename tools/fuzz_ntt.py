@@ -64,7 +64,7 @@ def main():
             print(f"{it + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     print(f"done: {cases} cases, {bad} mismatches")
     from panda_amd import gpu_ffi as _ffi
-    _ffi.load().panda_ntt_set_streamed_tables(1)
+    _ffi.load().panda_ntt_set_streamed_tables(0xFFFFFFFF)
     gm.deinit()
     sys.exit(1 if bad else 0)
 

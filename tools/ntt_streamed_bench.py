@@ -48,7 +48,7 @@ def main():
                     ds.append(ms.value)
                 ds.sort()
                 res[on].append(ds[len(ds) // 2])
-        lib.panda_ntt_set_streamed_tables(0)
+        lib.panda_ntt_set_streamed_tables(0xFFFFFFFF)
         for on in (0, 1):
             v = sorted(res[on])
             print(f"NTT bn254 2^{k} streamed table {'on ' if on else 'off'}: median of round medians {v[len(v)//2]:.4f} ms   rounds: " + " ".join(f"{x:.4f}" for x in res[on]), flush=True)

@@ -30,9 +30,30 @@ def short(k):
     return name
 
 
+def by_grid(tag):
+    """rocprofv3's kernel_stats.csv averages a kernel over ALL its launches -- k_accumulate's 2^24-point launches together with the 2^16-point
+    launch of the config-1 check (the printed 12.75 ms was not the 2^24 figure).  This table splits every kernel's launches by
+    grid size, from the kernel trace of the same pass."""
+    trace = latest("gpurun_out/prof_stats/**/*kernel_trace.csv")
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")) if "Grid_Size_X" in r else str(r.get("Grid_Size", ""))
+        wg = "x".join(str(r.get(k, "")) for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z")) if "Workgroup_Size_X" in r else str(r.get("Workgroup_Size", ""))
+        groups[(short(r["Kernel_Name"]), grid, wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    path = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_by_grid.csv")
+    with open(path, "w") as o:
+        o.write("# rocprofv3 --kernel-trace of the stats pass (tools/profile_bench.sh), every kernel's launches split by grid size; durations in ms\n")
+        o.write("kernel,grid_threads,workgroup,launches,avg_ms,min_ms,max_ms,total_ms\n")
+        for (k, grid, wg), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            if re.match(r"k\d?_", k):
+                o.write("%s,%s,%s,%d,%.4f,%.4f,%.4f,%.3f\n" % (k, grid, wg, len(v), sum(v) / len(v), min(v), max(v), sum(v)))
+    print(open(path).read()[:2500])
+
+
 def main():
     tag = sys.argv[1]
     shutil.copy(latest("gpurun_out/prof_stats/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
+    by_grid(tag)
     res = {}
     for name in ("fetch", "write"):
         agg = collections.defaultdict(list)
