@@ -474,16 +474,12 @@ PandaGpuError PandaMultiGpuManager::msm_bn254_with_cached_bases(Bytes scalars, s
     result->assign(3 * FIELD_ELEMENT_LEN, 0);
     // every device uploads its own shard inside the call, in point ranges beside its kernels (round 3 copied the G shards one after the
     // other from this thread before anything ran: unit.rs:103-188 stages the same way)
-    bool ok = panda_msm_execute_bn254_from_host_multi(handle, cfgs.data(), h_scalars.data(), 4, result->data()) == 0;
-    if (!ok) {
-        // the one-call path has only ever run over RCCL with one rank (README, "Not validated on hardware"): should it fail on a real
-        // node, stage the way round 3 did -- every shard uploaded from this thread, then the sharded execute on resident scalars
-        fprintf(stderr, "[panda-hip] panda_msm_execute_bn254_from_host_multi failed: staging the shards, then panda_msm_execute_bn254_multi\n");
-        ok = true;
-        for (size_t d = 0; ok && d < G; d++)
-            ok = set_device((size_t)devices_[d]) == PandaGpuError::Ok && panda_memcpy(cfgs[d].scalars, const_cast<void *>(h_scalars[d]), per * FIELD_ELEMENT_LEN) == 0;
-        ok = ok && panda_msm_execute_bn254_multi(handle, cfgs.data(), result->data()) == 0;
-    }
+    // (Round 5 fell back to "upload every shard from this thread, then panda_msm_execute_bn254_multi" when this call failed, because the one-call
+    // path had only ever run over RCCL with one rank.  It has since run at 2 / 4 / 8 ranks under the RCCL interposer (tests/test_fake_rccl.py),
+    // and a silent second attempt hid the error code and repeated the work after a device fault: a failure is now reported as it is.)
+    const panda_error pe = panda_msm_execute_bn254_from_host_multi(handle, cfgs.data(), h_scalars.data(), 4, result->data());
+    const bool ok = pe == 0;
+    if (!ok) fprintf(stderr, "[panda-hip] panda_msm_execute_bn254_from_host_multi failed: panda_error %u\n", (unsigned)pe);
     (void)set_device((size_t)devices_[0]);
     return ok ? PandaGpuError::Ok : PandaGpuError::SchedulingErr;
 }

@@ -17,6 +17,13 @@ from panda_amd import multi_gpu
 pytestmark = pytest.mark.gpu
 
 
+def _soak(*values):
+    """a case of an off-by-default experiment path that only runs under `-m gpu_soak` (tests/conftest.py): `-m gpu` keeps one representative
+    case per path -- the fuzzers (tools/fuzz_msm.py, fuzz_ntt.py, fuzz_ranges.py) cover these paths at random"""
+    return pytest.param(*values, marks=pytest.mark.gpu_soak)
+
+
+
 @pytest.fixture(scope="module")
 def gm():
     m = pgm.PandaGpuManager(0)
@@ -1641,11 +1648,12 @@ def test_msm_precomputed_tables_skewed_2_15(gm, kind):
 
 
 @pytest.mark.parametrize("cid,k,wbits,front,wgs,kind", [
-    (0, 13, 19, 64, 6, "uniform"), (0, 15, 20, 32, 4, "uniform"), (0, 16, 22, 8, 6, "uniform"), (0, 16, 22, 120, 2, "uniform"), (0, 14, 21, 1, 64, "uniform"),
-    (0, 14, 22, 40, 6, "zeros"), (0, 14, 22, 40, 6, "ones"), (0, 14, 22, 40, 6, "minus_one"), (0, 14, 22, 40, 6, "small"), (0, 14, 22, 40, 6, "all_equal"),
-    (0, 14, 22, 40, 6, "half_zero"), (0, 14, 22, 40, 6, "top_bit"), (0, 18, 22, 32, 6, "uniform"), (0, 20, 0, 32, 6, "uniform"), (1, 14, 20, 32, 0, "uniform"),
-    (2, 13, 19, 64, 0, "uniform"), (1, 2, 22, 121, 8, "uniform"), (1, 2, 20, 113, 6, "uniform"), (0, 3, 22, 100, 64, "uniform"), (0, 5, 21, 127, 8, "uniform"),
-    (0, 6, 22, 64, 64, "small_tiny")])
+    (0, 13, 19, 64, 6, "uniform"), (0, 14, 22, 40, 6, "all_equal"), (1, 14, 20, 32, 0, "uniform"),
+    _soak(0, 15, 20, 32, 4, "uniform"), _soak(0, 16, 22, 8, 6, "uniform"), _soak(0, 16, 22, 120, 2, "uniform"), _soak(0, 14, 21, 1, 64, "uniform"),
+    _soak(0, 14, 22, 40, 6, "zeros"), _soak(0, 14, 22, 40, 6, "ones"), _soak(0, 14, 22, 40, 6, "minus_one"), _soak(0, 14, 22, 40, 6, "small"),
+    _soak(0, 14, 22, 40, 6, "half_zero"), _soak(0, 14, 22, 40, 6, "top_bit"), _soak(0, 18, 22, 32, 6, "uniform"), _soak(0, 20, 0, 32, 6, "uniform"),
+    _soak(2, 13, 19, 64, 0, "uniform"), _soak(1, 2, 22, 121, 8, "uniform"), _soak(1, 2, 20, 113, 6, "uniform"), _soak(0, 3, 22, 100, 64, "uniform"), _soak(0, 5, 21, 127, 8, "uniform"),
+    _soak(0, 6, 22, 64, 64, "small_tiny")])
 def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, wbits, front, wgs, kind):
     """panda_msm_set_overlap: with tables, levels 2 and 3 of the sort for the back of the bucket space run on a second stream beside the
     accumulation of the front (a launch of a few workgroups per CU), then the rest is accumulated.  Same group element as the oracle
@@ -1690,8 +1698,12 @@ def test_msm_sort_of_the_rest_beside_the_accumulation_of_the_front(gm, cid, k, w
         d.free()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
-@pytest.mark.parametrize("k,wbits,kind", [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (13, 14, "all_equal"), (13, 14, "half_zero"), (13, 14, "small"), (13, 0, "plain")])
+_LDS_ROW_CASES = [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (13, 14, "all_equal"), (13, 14, "half_zero"), (13, 14, "small"), (13, 0, "plain")]
+
+
+@pytest.mark.parametrize("variant,k,wbits,kind", [(0,) + c for c in _LDS_ROW_CASES]  # variant 0 is the built-in kernel: identity rows, skew, plain path
+                         + [(1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain")]
+                         + [_soak(v, *c) for v in (1, 2, 3) for c in _LDS_ROW_CASES if (v,) + c not in ((1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"))])
 def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
     """panda_msm_set_accumulate_variant: k_accumulate with the next entry's row staged in LDS (global_load_lds) at five / four waves per
     SIMD -- the same group element as the oracle says, with tables and on the plain path, uniform and skewed scalars, identity rows"""
@@ -1721,8 +1733,11 @@ def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
         d.free()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
-@pytest.mark.parametrize("k,wbits,kind", [(15, 14, "all_equal"), (16, 14, "all_equal"), (15, 0, "ones"), (14, 12, "small"), (16, 0, "half_zero"), (15, 16, "top_bit"), (17, 0, "uniform")])
+_WIDE_MERGE_CASES = [(15, 14, "all_equal"), (16, 14, "all_equal"), (15, 0, "ones"), (14, 12, "small"), (16, 0, "half_zero"), (15, 16, "top_bit"), (17, 0, "uniform")]
+_WIDE_MERGE_KEPT = [(1, 15, 14, "all_equal"), (1, 16, 14, "all_equal"), (2, 16, 14, "all_equal"), (3, 17, 0, "uniform")]  # mode 1 is what the policy picks from 2^24 points up
+
+
+@pytest.mark.parametrize("mode,k,wbits,kind", _WIDE_MERGE_KEPT + [_soak(m, *c) for m in (1, 2, 3) for c in _WIDE_MERGE_CASES if (m,) + c not in _WIDE_MERGE_KEPT])
 def test_msm_level3_merge_wide_variant(gm, mode, k, wbits, kind):
     """panda_msm_set_wide_merge: every level-3 cell through the variant of k3_merge that reads up to 32 k entries per cell once and writes
     them in two rounds (mode 1), or none (mode 2: large cells take the two-pass path).  2^15 equal scalars put exactly 32 k entries into
@@ -1752,7 +1767,7 @@ def test_msm_level3_merge_wide_variant(gm, mode, k, wbits, kind):
         d.free()
 
 
-@pytest.mark.parametrize("cid,k,tables", [(1, 14, True), (2, 13, True), (3, 12, True), (1, 12, False), (3, 11, False), (0, 16, True)])
+@pytest.mark.parametrize("cid,k,tables", [(1, 14, True), (3, 11, False), _soak(2, 13, True), _soak(3, 12, True), _soak(1, 12, False), _soak(0, 16, True)])
 def test_msm_accumulate_with_rows_fetched_four_lanes_to_a_row(gm, cid, k, tables):
     """panda_msm_set_accumulate_variant(3) on every curve (rows of 64, 96 and 128 bytes: 4, 6, 8 pieces a row), tables and plain path"""
     lib = ffi.load()
