@@ -51,7 +51,7 @@ MAD_BARE_CHAIN_PER_S = 33.4e12
 # (counted in the ISA of k_accumulate<Bn254Fq>)
 MADS_PER_ADDITION_BN254 = 1467
 # the same count for a 14-limb base field (BLS12-377 / BLS12-381): 8 * 2 * 14^2 + 2 * (14 * 15 / 2 + 14^2) - 14^2
-MADS_PER_ADDITION = {0: 1467, 1: 3542, 2: 3542}
+MADS_PER_ADDITION = {0: 1467, 1: 3416, 2: 3542}  # BLS12-377: minus 9 reductions x 14 products by the zero top limb of p (fe29.h, fe29_reduce_col)
 # Operation-count MODEL of the reference's CUDA MSM on this chip: per call
 # n * W * 11 mulmods of Jacobian mixed additions (msm_cuda.cuh:373-409) + B * ~370 for weighting and reducing the B = W (2^c - 1)
 # buckets (msm_cuda.cuh:411-449, 451-497) at its fixed c = 16, W = 16, priced at the measured rate of the reference's own kind of

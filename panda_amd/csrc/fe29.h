@@ -140,12 +140,21 @@ template <class F, int K>
 __device__ inline __attribute__((always_inline)) void fe29_reduce_col(uint64_t &acc, uint32_t *m, uint32_t *out)
 {
     constexpr int N = F::N;
+    // A modulus whose top limb is zero (BLS12-377 Fq: 377 bits = 13 x 29 exactly, held in 14 limbs for the lazy-reduction headroom) has one
+    // product m_i * P[N-1] = 0 in each of the columns N-1 .. 2N-2: they are not issued (14 of the 392 multiply-adds of a product).
+    constexpr bool TOP0 = F::P[N - 1] == 0;
     if constexpr (K < N) {
-        MacChain<K>::vs(acc, m, &F::P[K]);
+        if constexpr (TOP0 && K == N - 1)
+            MacChain<K - 1>::vs(acc, m + 1, &F::P[K - 1]);
+        else
+            MacChain<K>::vs(acc, m, &F::P[K]);
         m[K] = ((uint32_t)acc * F::INV) & ((1u << 29) - 1);
         MacChain<1>::vs(acc, m + K, &F::P[0]);
     } else {
-        MacChain<2 * N - 1 - K>::vs(acc, m + (K - N + 1), &F::P[N - 1]);
+        if constexpr (TOP0)
+            MacChain<2 * N - 2 - K>::vs(acc, m + (K - N + 2), &F::P[N - 2]);
+        else
+            MacChain<2 * N - 1 - K>::vs(acc, m + (K - N + 1), &F::P[N - 1]);
         out[K - N] = (uint32_t)acc & ((1u << 29) - 1);
     }
     acc >>= 29;

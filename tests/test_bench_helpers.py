@@ -40,7 +40,8 @@ def test_plain_window_counts():
     assert b.plain_windows(lib, 1, 24) == 13  # BLS12-377 Fr: 253 bits
     assert 16 <= b.plain_windows(lib, 0, 12) <= 40
     assert b.MADS_PER_ADDITION[0] == 8 * 162 + 2 * 126 - 81
-    assert b.MADS_PER_ADDITION[1] == 8 * 2 * 14 * 14 + 2 * (14 * 15 // 2 + 14 * 14) - 14 * 14
+    assert b.MADS_PER_ADDITION[2] == 8 * 2 * 14 * 14 + 2 * (14 * 15 // 2 + 14 * 14) - 14 * 14
+    assert b.MADS_PER_ADDITION[1] == b.MADS_PER_ADDITION[2] - 9 * 14  # BLS12-377 Fq: the modulus' top 29-bit limb is zero, 14 products fewer in each of the 9 reductions
 
 
 def test_argument_surface(monkeypatch):

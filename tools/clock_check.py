@@ -3,7 +3,7 @@ round's built from its commit): per launch the HIP-event milliseconds and -- whe
 (panda_set_clock_stamps: shader cycles and 10 ns ticks around the launch).  Run under `rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace`
 (tools/clock_check.sh) the counter gives the same launches' cycles from outside: GRBM_GUI_ACTIVE / 8 (the profiler sums the 8 XCDs).
 Binds only the handful of symbols it needs, so that a round-4 library (fewer exports) loads.
-usage: clock_check.py [log_n=24] [launches=12]"""
+usage: clock_check.py [log_n=24] [launches=12] [curve=0]   (curve 1: BLS12-377, 2: BLS12-381)"""
 import ctypes as C
 import json
 import os
@@ -25,6 +25,8 @@ class Cfg(C.Structure):
 def main():
     log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     launches = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    curve = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    point = (64, 96, 96)[curve]
     try:
         import torch  # noqa: F401  (one libamdhip64 in the process, as panda_amd.gpu_ffi does)
     except Exception:
@@ -34,7 +36,8 @@ def main():
     lib.panda_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.panda_gen_bases.argtypes = lib.panda_gen_scalars.argtypes = [u, u64, u64, u64, vp, Handle]
     lib.panda_msm_precompute_bases.argtypes = [u, vp, u, u, Handle]
-    lib.panda_msm_execute_bn254.argtypes = [Cfg]
+    execute = (lib.panda_msm_execute_bn254, lib.panda_msm_execute_bls12_377, lib.panda_msm_execute_bls12_381)[curve]
+    execute.argtypes = [Cfg]
     lib.panda_msm_set_phase_timing.argtypes = [u]
     lib.panda_msm_last_phase_ms.argtypes = [C.POINTER(C.c_float)]
     lib.panda_stream_create.argtypes = [C.POINTER(Handle), C.c_bool]
@@ -45,13 +48,13 @@ def main():
 
     n = 1 << log_n
     db, ds, dr = vp(), vp(), vp()
-    for p, size in ((db, n * 64), (ds, n * 32), (dr, 96)):
+    for p, size in ((db, n * point), (ds, n * 32), (dr, 144)):
         ok(lib.panda_malloc(C.byref(p), size), "malloc")
     null, stream = Handle(), Handle()
     ok(lib.panda_stream_create(C.byref(stream), False), "stream")
-    ok(lib.panda_gen_bases(0, 1, 0, n, db, null), "gen_bases")
-    ok(lib.panda_gen_scalars(0, 2, 0, n, ds, null), "gen_scalars")
-    ok(lib.panda_msm_precompute_bases(0, db, log_n, 0, stream), "precompute")
+    ok(lib.panda_gen_bases(curve, 1, 0, n, db, null), "gen_bases")
+    ok(lib.panda_gen_scalars(curve, 2, 0, n, ds, null), "gen_scalars")
+    ok(lib.panda_msm_precompute_bases(curve, db, log_n, 0, stream), "precompute")
     stamps = hasattr(lib, "panda_set_clock_stamps")
     if stamps:
         lib.panda_set_clock_stamps.argtypes = [u]
@@ -62,7 +65,7 @@ def main():
     ph, clk = (C.c_float * 8)(), (u64 * 12)()
     rows = []
     for i in range(launches + 3):
-        ok(lib.panda_msm_execute_bn254(cfg), "msm")
+        ok(execute(cfg), "msm")
         lib.panda_msm_last_phase_ms(ph)
         row = {"k_accumulate_ms": round(ph[3], 4), "device_ms": round(ph[7], 4)}
         if stamps:
@@ -73,7 +76,7 @@ def main():
         if i >= 3:  # the first launches carry the chip from idle to its sustained clock
             rows.append(row)
     mean = {k: round(sum(r[k] for r in rows) / len(rows), 4) for k in rows[0]}
-    print("CLOCK_CHECK " + json.dumps({"lib": os.path.basename(LIB), "log_n": log_n, "launches": len(rows), "mean": mean, "rows": rows}), flush=True)
+    print("CLOCK_CHECK " + json.dumps({"lib": os.path.basename(LIB), "log_n": log_n, "curve": curve, "launches": len(rows), "mean": mean, "rows": rows}), flush=True)
 
 
 if __name__ == "__main__":
