@@ -179,6 +179,24 @@ __device__ __forceinline__ void load_words(u32 *dst, const u32 *src)
     }
 }
 
+// the same with the non-temporal hint: data that is read exactly once (the table rows k_accumulate gathers) should not push data that is
+// read again (the sorted words, four 16-byte loads per 64-byte sector, minutes of cache time apart) out of the L2
+template <int WORDS>
+__device__ __forceinline__ void load_words_stream(u32 *dst, const u32 *src)
+{
+    static_assert(WORDS % 4 == 0, "vector loads");
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u *s4 = reinterpret_cast<const v4u *>(src);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; i++) {
+        const v4u v = __builtin_nontemporal_load(&s4[i]);
+        dst[4 * i] = v.x;
+        dst[4 * i + 1] = v.y;
+        dst[4 * i + 2] = v.z;
+        dst[4 * i + 3] = v.w;
+    }
+}
+
 template <int WORDS>
 __device__ __forceinline__ void store_words(u32 *dst, const u32 *src)
 {
@@ -335,7 +353,11 @@ struct PackedBase {
 template <class F>
 __device__ __forceinline__ void fetch_base(PackedBase<F> &b, const u32 *bases, u32 entry)
 {
+#if defined(PANDA_ROWS_NT)
+    load_words_stream<2 * F::L>(b.w, bases + (u64)(entry & PANDA_ROW_MASK) * 2 * F::L);
+#else
     load_words<2 * F::L>(b.w, bases + (u64)(entry & PANDA_ROW_MASK) * 2 * F::L);
+#endif
 }
 
 // RAW: a negated y comes back un-normalised (limbs < 2^31) -- good enough for the one product it feeds in
