@@ -88,6 +88,9 @@ def parse():
                     help="ONE process drives all --gpus devices through the C entry points (panda_msm_execute_bn254_multi / panda_ntt_execute_bn254_multi: "
                          "a worker thread and an RCCL communicator per device inside the library) instead of one torch.distributed rank per GPU")
     ap.add_argument("--loopback", action="store_true", help="--single-process rehearsal on a one-GPU box: every rank on device 0, device copies instead of RCCL")
+    ap.add_argument("--rccl-on-device0", action="store_true",
+                    help="--single-process rehearsal on a one-GPU box: every rank on device 0 over the RCCL transport itself -- only under the test-only RCCL "
+                         "interposer (LD_PRELOAD=tests/fake_rccl/libfake_rccl.so with PANDA_TEST_SHARED_DEVICE_RCCL=1 FAKE_RCCL_ALLOW_SHARED_DEVICE=1, tests/test_fake_rccl.py)")
     ap.add_argument("--no-c-abi-leg", action="store_true", help="N > 1: do not run the single-process C-ABI leg after the torch.distributed legs")
     ap.add_argument("--launcher-note", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--detail", default=None, help="also write the un-shortened record (every leg's full dictionary) to this file; "
@@ -167,6 +170,17 @@ class Ctx:
             step(True)
         self.fence()
         return self.max_over_ranks(time.perf_counter() - t0)
+
+
+def device_identity(ctx) -> str:
+    """which device ran this line (arch, CUs, the tail of its UUID): with `sclk_mhz` and `k_accumulate_mcycles` beside the milliseconds, two
+    records that differ can be read as another device, another clock or another kernel"""
+    try:
+        p = ctx.torch.cuda.get_device_properties(ctx.dev)
+        uuid = str(getattr(p, "uuid", "") or "")
+        return f"{getattr(p, 'gcnArchName', p.name).split(':')[0]}/{p.multi_processor_count}cu/{uuid[-12:] if uuid else 'no-uuid'}"
+    except Exception as e:  # noqa: BLE001
+        return f"unknown ({type(e).__name__})"
 
 
 class MsmProblem:
@@ -273,11 +287,11 @@ def single_process(args) -> dict:
     lib = ffi.load()
     lib.panda_msm_set_phase_timing(1)  # per-rank k_accumulate / device times are part of this mode's line
     G = args.gpus
-    devices = [0] * G if args.loopback else list(range(G))
+    devices = [0] * G if (args.loopback or args.rccl_on_device0) else list(range(G))
     transport = ffi.MULTI_LOOPBACK if args.loopback else ffi.MULTI_RCCL
     mg = multi_gpu.MultiGpu(devices, transport)
     null = ffi.PandaStream()
-    how = "device copies, all ranks on device 0 (rehearsal)" if args.loopback else "RCCL"
+    how = "device copies, all ranks on device 0 (rehearsal)" if args.loopback else ("RCCL call sites under the test interposer, all ranks on device 0 (rehearsal)" if args.rccl_on_device0 else "RCCL")
 
     def alloc(dev, nbytes):
         ffi.check(lib.panda_set_device(dev), "SetDeviceError")
@@ -533,7 +547,7 @@ def contract_line(full: dict) -> dict:
                 kms[short + "_issue_frac"] = _sig(f, 3)
     if kms:
         line["k_accumulate_ms"] = kms
-    for k in ("device_ms_per_step", "device_ms_by_rank"):
+    for k in ("device_ms_per_step", "device_ms_by_rank", "device"):
         if k in full:
             line[k] = _sig(full[k]) if isinstance(full[k], float) else full[k]
     for leg, v in full.items():
@@ -692,6 +706,7 @@ def main():
                          "k_accumulate_mcycles": acc_mcycles, "sclk_mhz": acc_sclk_mhz},
             "phases_ms": {nm: round(v, 4) for nm, v in zip(names, mean)},
             "device_ms_per_step": device_ms,
+            "device": device_identity(ctx),
         }
         if world == 1:
             ref_ms = reference_model_ms(log_n)

@@ -94,3 +94,22 @@ def test_cpp_manager_test_over_rccl_under_the_interposer(tmp_path):
     assert "manager_test: all ok" in r.stdout and "4 rank(s), RCCL transport" in r.stdout
     text = open(log).read()
     assert "FAIL" not in text and "4 rank(s) on device(s) 0,0,0,0" in text and "16 matched send/recv pair(s)" in text and "2 rank(s) on device(s) 0,0" in text
+
+
+@pytest.mark.gpu
+def test_bench_single_process_leg_over_rccl_under_the_interposer(tmp_path):
+    """`bench.py --gpus 4 --single-process` -- the C-ABI leg the driver's N > 1 runs end with (one process, panda_*_multi over RCCL) -- rehearsed with
+    four ranks on device 0 over the RCCL transport under the interposer: one contract line with the sharded MSM, config 4's shape and the sharded NTT legs."""
+    log = str(tmp_path / "fake_rccl_bench.log")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--single-process", "--rccl-on-device0", "--steps", "1", "--warmup", "0", "--log-n", "18",
+           "--config4-total-log-n", "20", "--detail", str(tmp_path / "detail.json")]
+    env = {k: v for k, v in _child_env(log).items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["value"] > 0 and "interposer" in line["config"]["exchange"]
+    ms = line["configs_ms"]
+    assert ms["c4_msm_2_26_total"] > 0 and ms["ntt_sharded_2_24_total"] > 0 and ms["ntt_sharded_batch4_per_transform"] > 0 and ms["msm_2_24_from_host_one_call"] > 0
+    text = open(log).read()
+    assert "FAIL" not in text and "4 rank(s) on device(s) 0,0,0,0" in text and "16 matched send/recv pair(s)" in text and "all-gather(s) over 4 rank-call(s)" in text
