@@ -222,6 +222,7 @@ hipError_t release_thread_arena()
 {
     g_helper.drop();
     g_mailbox.drop();
+    g_stamp_blocks.drop();
     return thread_arena().release();
 }
 
