@@ -205,6 +205,7 @@ class MsmProblem:
         if register:
             self.register(tables)
         self.total = None
+        self.last_mcycles = self.last_sclk_mhz = None
 
     def register(self, tables: bool):
         """"cached bases" (BASELINE config): the base set stays on the device across MSMs and is registered once, so the
@@ -256,16 +257,25 @@ class MsmProblem:
 
     def timed_phases(self, level: int, reps: int = 3):
         """mean phase times of `reps` extra, untimed calls at phase-timer level `level` (1: the total and k_accumulate); the library's
-        default -- what a timed step runs at unless it says otherwise -- records no device timers at all"""
+        default -- what a timed step runs at unless it says otherwise -- records no device timers at all.  The same calls carry the clock
+        stamps around k_accumulate: self.last_mcycles / self.last_sclk_mhz (means over the calls; None when nothing was stamped)."""
         lib = self.ctx.lib
         lib.panda_msm_set_phase_timing(level)
+        lib.panda_set_clock_stamps(1)
+        clk = (C.c_uint64 * self.ctx.ffi.CLOCK_WORDS)()
         try:
-            rows = []
+            rows, cyc = [], []
             for _ in range(reps):
                 self.execute()
                 rows.append(self.phases())
+                lib.panda_msm_last_clock(clk)
+                if clk[1] and clk[2]:
+                    cyc.append((int(clk[0]) / 1e6, int(clk[3]) / int(clk[1]) * 100.0))
         finally:
+            lib.panda_set_clock_stamps(0)
             lib.panda_msm_set_phase_timing(0)
+        self.last_mcycles = sum(c[0] for c in cyc) / len(cyc) if cyc else None
+        self.last_sclk_mhz = sum(c[1] for c in cyc) / len(cyc) if cyc else None
         return [sum(r[i] for r in rows) / len(rows) for i in range(8)]
 
     def release(self):
@@ -545,6 +555,9 @@ def contract_line(full: dict) -> dict:
             f = _get(full, leg, "with_tables", "roofline_issue", "frac")
             if f:
                 kms[short + "_issue_frac"] = _sig(f, 3)
+            c = _get(full, leg, "with_tables", "k_accumulate_mcycles")
+            if c:
+                kms[short + "_mcycles"] = _sig(c, 5)
     if kms:
         line["k_accumulate_ms"] = kms
     for k in ("device_ms_per_step", "device_ms_by_rank", "device"):
@@ -830,6 +843,7 @@ def small_config(ctx: Ctx, curve: int, log_n: int, coord: int, steps: int, what:
         dt = ctx.timed(lambda _t: prob.execute(), 2, steps) / steps  # no device timers inside these steps (the library's default)
         ph = prob.timed_phases(1, 3)                                 # k_accumulate and the device total: three separate calls
         res[label] = {"value": prob.n / dt, "ms_per_step": dt * 1e3, "bases": prob.mode, "k_accumulate_ms": ph[3], "device_ms": ph[7],
+                      "k_accumulate_mcycles": prob.last_mcycles, "sclk_mhz": prob.last_sclk_mhz,
                       "roofline_frac_hbm": BYTES_PER_POINT[curve] * prob.n / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if curve in MADS_PER_ADDITION and ph[3] > 0:
             # the bound that binds: one mixed addition per sorted entry -- W n with tables, windows * n without
