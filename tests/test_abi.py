@@ -198,3 +198,39 @@ def test_g2_host_entry_point_vs_python_reference():
                        for h in range(2)])
     total = multi_gpu.combine_partials(halves, curve=pgm.BN254_G2)
     assert pyref.g2_decode_jacobian(total.view(np.uint32)) == want
+
+
+def test_clock_delta_pairs_stamps_per_cu_and_reports_the_slowest_xcd():
+    """panda_clock_delta is host code (no GPU needed): two stamp blocks of [xcc 0..7][256 CU slots][s_memtime, s_memrealtime] -> cycles of the XCD
+    that showed the fewest, ticks, XCDs paired, mean over the XCDs, per-XCD cycles.  Stamps are paired per CU slot: a CU stamped on one side
+    only is ignored, and CU counters with wildly different offsets (s_memtime is per CU) do not disturb the deltas."""
+    import numpy as np
+
+    lib = ffi.load()
+    rng = np.random.default_rng(6)
+    before = np.zeros((8, 256, 2), dtype=np.uint64)
+    after = np.zeros((8, 256, 2), dtype=np.uint64)
+    clocks = [2049, 1989, 2025, 1943, 1999, 1949, 2003, 1941]  # MHz per XCD
+    ticks = 1_400_000  # 14 ms in 10 ns ticks
+    for x in range(8):
+        for cu in range(32):
+            slot = (cu % 16) | ((cu // 16) << 5)            # some HW_ID[15:8] pattern
+            base = int(rng.integers(1 << 40, 1 << 48))      # every CU's counter has its own offset
+            t0 = 5_000_000_000 + int(rng.integers(0, 50))
+            before[x, slot] = (base, t0)
+            after[x, slot] = (base + clocks[x] * ticks // 100 + int(rng.integers(0, 2000)), t0 + ticks + int(rng.integers(0, 20)))
+    before[3, 200] = (123, 456)          # stamped before only: ignored
+    after[5, 201] = (999, 5_100_000_000)  # stamped after only: ignored
+    out = (C.c_uint64 * ffi.CLOCK_WORDS)()
+    assert lib.panda_clock_delta(C.c_void_p(before.ctypes.data), C.c_void_p(after.ctypes.data), out) == 0
+    cycles, tk, xcds, mean = out[0], out[1], out[2], out[3]
+    per = list(out[4:12])
+    assert xcds == 8 and abs(tk - ticks) < 40
+    for x in range(8):
+        assert abs(per[x] - clocks[x] * ticks // 100) < 3000, (x, per[x])
+    assert cycles == min(per) and per.index(cycles) == 7            # XCD 7 holds the lowest clock
+    assert abs(mean - sum(per) // 8) <= 1
+    assert abs(mean / tk * 100.0 - sum(clocks) / 8) < 1.0           # MHz of the box
+    # nothing paired: all zeros, not garbage
+    assert lib.panda_clock_delta(C.c_void_p(before.ctypes.data), C.c_void_p(before.ctypes.data), out) == 0 and list(out) == [0] * ffi.CLOCK_WORDS
+    assert lib.panda_clock_delta(None, C.c_void_p(after.ctypes.data), out) == 1
