@@ -208,7 +208,9 @@ panda_error panda_msm_set_chunk_entries(unsigned entries);
 panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per_cu);
 /* Experiments on the bucket-accumulation kernel of the 9-limb base fields (BN254): 0 = the built-in choice, 1 = five waves per SIMD with
  * the next entry's table row staged in LDS (global_load_lds) instead of registers, 2 = four waves per SIMD with the staged row, 3 = (every
- * curve) the rows of a wave fetched four lanes to a row into LDS (profiles/r05_accumulate_table_footprint.txt).  Same group element. */
+ * curve) the rows of a wave fetched four lanes to a row into LDS (profiles/r05_accumulate_table_footprint.txt), 4 = (every curve) a
+ * chunk's sorted words in whole 64-byte sectors through LDS -- built in for the 9-limb fields from round 6 on --, 5 = never (sixteen-byte
+ * global loads, as rounds 2-5 did; profiles/r06_accumulate_fetch_and_row_loads.txt).  Same group element. */
 panda_error panda_msm_set_accumulate_variant(unsigned variant);
 /* Level-3 merge of the bucket sort (tabled calls): 0 = built-in (the cells of the lower half of the bucket space, which hold up to twice
  * the mean when the plan mixes two window widths, go through the variant that reads up to 32 k entries per cell once, those of the upper

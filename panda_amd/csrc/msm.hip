@@ -634,7 +634,7 @@ panda_error panda_msm_set_overlap(unsigned front_of_128, unsigned workgroups_per
 
 panda_error panda_msm_set_accumulate_variant(unsigned variant)
 {
-    if (variant > 3) return panda_error_invalid_value;
+    if (variant > 5) return panda_error_invalid_value;
     g_acc_variant.store(variant, std::memory_order_relaxed);
     return panda_success;
 }

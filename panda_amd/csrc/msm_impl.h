@@ -59,7 +59,7 @@ struct MsmTuning {
     unsigned overlap_front; // with tables: size of the front part of the bucket space, in 1/128, whose accumulation runs beside the sort of the rest (0 = no overlap)
     unsigned overlap_wgs;   // workgroups per CU of that accumulation (6 = three waves per SIMD); 0 = the curve's default
     unsigned chunk_first;   // 1 (built in): k_chunk_first hands every chunk of k_accumulate its first bucket; 0: every thread searches the offsets for it (round 1-5)
-    unsigned acc_variant;   // experiments on k_accumulate: 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it (9-limb fields), 3 = rows fetched four lanes to a row (k_accumulate_shared)
+    unsigned acc_variant;   // experiments on k_accumulate: 0 = the built-in kernel, 1 = five waves per SIMD with the next row staged in LDS, 2 = four waves with it (9-limb fields), 3 = rows fetched four lanes to a row (k_accumulate_shared), 4 = the sorted words in 64-byte sectors through LDS for every field (built in for the 9-limb fields), 5 = never (sixteen-byte global loads, rounds 2-5)
 };
 
 // Point-range pipeline inside one call (the reference's three streams, wrapper.rs:260-273, unit.rs:17-29, serialise
@@ -427,9 +427,14 @@ __device__ __forceinline__ void read_base_lds(PackedBase<F> &b, const uint4 *lds
     }
 }
 
-template <class F, bool LDSROW>
+// SWLDS (experiment, panda_msm_set_accumulate_variant(4)): the chunk's sorted words travel in whole 64-byte sectors -- four
+// global_load_lds per sixteen entries into one of two 64-byte-per-lane LDS buffers of the wave, a ds_read_b128 per four entries -- instead
+// of one 16-byte global load per four entries.  A lane walks its own stretch of the list, so its four loads of one sector are four
+// additions (~18 us) apart, and by then the sector has left the L2: FETCH_SIZE counts the sorted words (0.8 GB at 2^24) about four times.
+// lds_words: the wave's 2 buffers x 4 pieces x 64 lanes of uint4.
+template <class F, bool LDSROW, bool SWLDS = false>
 __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, const u32 *__restrict__ sw, const u32 *__restrict__ ow, u32 *__restrict__ bw, u32 *__restrict__ pw,
-                                                 u32 b, u32 start, u32 end, uint4 *lds_wave, unsigned lane)
+                                                 u32 b, u32 start, u32 end, uint4 *lds_wave, unsigned lane, uint4 *lds_words = nullptr)
 {
     constexpr int PW = 4 * F::N;
     u32 next = ow[b + 1];
@@ -448,8 +453,26 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
     // entry fetched the same 64-byte sector sixteen times over -- long after the L2 had let go of it (FETCH_SIZE: 17.8 GB per launch
     // against 12.9 GB of rows + 0.8 GB of words).
     const bool quads = ((reinterpret_cast<uintptr_t>(sw + start) & 15) == 0); // chunk starts are multiples of K >= 16 words; tiny lists may not be aligned
+    // sectors: the chunk starts on 64 bytes (K a multiple of 16 words); sector s of the chunk sits in buffer s & 1
+    const bool sectors = SWLDS && ((reinterpret_cast<uintptr_t>(sw + start) & 63) == 0);
+    auto sector_to_lds = [&](u32 sector) { // at most 60 bytes past the list's end, inside the arena
+        const u32 *src = sw + start + 16 * sector;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * q),
+                                             (__attribute__((address_space(3))) void *)(lds_words + (sector & 1u) * 256 + q * 64), 16, 0, 0);
+    };
     uint4 quad = make_uint4(0, 0, 0, 0);
-    if (quads) quad = *reinterpret_cast<const uint4 *>(sw + start); // at most 12 bytes past the list's end, inside the arena
+    if constexpr (SWLDS) {
+        if (sectors) {
+            sector_to_lds(0);
+            if (start + 16 < end) sector_to_lds(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing else is in flight yet
+            quad = lds_words[lane];
+        } else if (quads)
+            quad = *reinterpret_cast<const uint4 *>(sw + start);
+    } else if (quads)
+        quad = *reinterpret_cast<const uint4 *>(sw + start); // at most 12 bytes past the list's end, inside the arena
     u32 cur_entry = quads ? quad.x : sw[start];
     u32 ahead_entry = quads ? quad.y : (start + 1 < end ? sw[start + 1] : 0u);
     if constexpr (LDSROW)
@@ -487,7 +510,16 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
             if (pos + 2 < end) {
                 if (quads) {
                     const u32 idx = pos + 2 - start;
-                    if ((idx & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(sw + pos + 2);
+                    if ((idx & 3u) == 0) {
+                        if (SWLDS && sectors) {
+                            // the sector was sent to LDS sixteen entries ago (or at the start), i.e. before the row gather that the top of this
+                            // iteration waited for: the counter is in order, so it has landed.  Entering sector s frees the other buffer (sector
+                            // s - 1 has been read to its end) for sector s + 1.
+                            if ((idx & 15u) == 0 && start + idx + 16 < end) sector_to_lds((idx >> 4) + 1);
+                            quad = lds_words[((idx >> 4) & 1u) * 256 + ((idx >> 2) & 3u) * 64 + lane];
+                        } else
+                            quad = *reinterpret_cast<const uint4 *>(sw + pos + 2);
+                    }
                     ahead_entry = (idx & 2u) ? ((idx & 1u) ? quad.w : quad.z) : ((idx & 1u) ? quad.y : quad.x);
                 } else
                     ahead_entry = sw[pos + 2];
@@ -524,7 +556,7 @@ __device__ __forceinline__ void accumulate_chunk(const u32 *__restrict__ bases, 
 // grid of one thread per chunk keeps the command processor placing workgroups for as long as it has chunks left, and the kernels of
 // the second stream are not even started until it is through (profiles/r05_overlap_sort_accumulate.txt, A); a grid that is placed in
 // one go leaves the dispatcher to them.  (Chunks handed out statically, t, t + threads, ..., ran 15 % slower: ibid., B.)
-template <class F, bool PERSIST, int WAVES = (F::N <= 9 ? 4 : 2), bool LDSROW = false>
+template <class F, bool PERSIST, int WAVES = (F::N <= 9 ? 4 : 2), bool LDSROW = false, bool SWLDS = false>
 __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict__ bases, const u32 *__restrict__ sorted, const u32 *__restrict__ off,
                                                     u32 *__restrict__ bucket_acc, u32 *__restrict__ parts, u64 stride, unsigned NB, unsigned K,
                                                     unsigned chunks, u32 *__restrict__ long_count, const u32 *__restrict__ stale, AccPart part,
@@ -549,6 +581,8 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
     u32 *bw = bucket_acc + (u64)w * NB * PW;
     __shared__ uint4 s_rows[LDSROW ? 2 * (2 * F::L / 4) * 64 : 1]; // a wave's region: 2 L / 4 pieces of 1 KB
     uint4 *lds_wave = s_rows + (threadIdx.x >> 6) * (LDSROW ? (2 * F::L / 4) * 64 : 0);
+    __shared__ uint4 s_words[SWLDS ? 2 * 512 : 1]; // a wave's region: two sector buffers of 4 pieces x 64 lanes x 16 bytes
+    uint4 *lds_words = s_words + (threadIdx.x >> 6) * (SWLDS ? 512 : 0);
     const unsigned lane = threadIdx.x & 63u;
     if constexpr (PERSIST) {
         const unsigned first = lo_pos / K; // the chunks before it end at or below lo_pos: an earlier launch's
@@ -569,7 +603,7 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
                 clamped = true; // the list's last, short chunk: no earlier launch took it (they only take whole chunks), even if it ends AT lo_pos
             }
             if (mine && (end > lo_pos || clamped))
-                accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane);
+                accumulate_chunk<F, LDSROW, SWLDS>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane, lds_words);
         }
     } else {
         const unsigned t = t0;
@@ -586,7 +620,7 @@ __global__ void __launch_bounds__(128, WAVES) k_accumulate(const u32 *__restrict
         // (a short last chunk may end exactly at lo_pos -- everything lies in the earlier launch's part -- and still belongs here: the earlier
         // launch only took whole chunks)
         if (end > lo_pos || clamped)
-            accumulate_chunk<F, LDSROW>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane);
+            accumulate_chunk<F, LDSROW, SWLDS>(bases, sw, ow, bw, parts + ((u64)w * chunks + t) * 2 * PW, fw ? fw[t] : owner_bucket(ow, search_hi, start), start, end, lds_wave, lane, lds_words);
     }
 }
 
@@ -1366,6 +1400,11 @@ hipError_t msm_execute(const panda_msm_configuration &cfg, const panda::MsmRegis
             if constexpr (Fq::N <= 9 && !IsExt2<Fq>::value) // four waves per SIMD with the LDS-staged row
                 hipLaunchKernelGGL((k_accumulate<Fq, false, 4, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts,
                                    g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr}, d_first);
+        } else if (!IsExt2<Fq>::value && (tuning.acc_variant == 4 || (tuning.acc_variant == 0 && Fq::N <= 9 && g.K % 16 == 0))) {
+            // the sorted words in whole 64-byte sectors through LDS: the built-in kernel of the 9-limb fields from round 6 on (k_accumulate's
+            // fetch 16.2 -> 13.7 GB per launch at 2^24, +0.5 % clock, -0.5 % time; neutral for the 14-limb fields: variant 4 forces it, 5 forbids it)
+            hipLaunchKernelGGL((k_accumulate<Fq, false, (Fq::N <= 9 ? 4 : 2), false, true>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off,
+                               target, d_parts, g.stride, NB, g.K, g.chunks, d_lcount, registered ? d_stale : nullptr, AccPart{nullptr, 0u, 0u, 1u, NB, nullptr}, d_first);
         } else if (tuning.acc_variant == 3) { // the wave's gathers four lanes to a row
             hipLaunchKernelGGL((k_accumulate_shared<Fq>), dim3((g.chunks + 127) / 128, lists), dim3(128), 0, ls, d_bases, sorted.sorted, sorted.off, target, d_parts, g.stride, NB,
                                g.K, g.chunks, d_lcount, registered ? d_stale : nullptr);

@@ -1702,11 +1702,13 @@ _LDS_ROW_CASES = [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (
 
 
 @pytest.mark.parametrize("variant,k,wbits,kind", [(0,) + c for c in _LDS_ROW_CASES]  # variant 0 is the built-in kernel: identity rows, skew, plain path
-                         + [(1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain")]
-                         + [_soak(v, *c) for v in (1, 2, 3) for c in _LDS_ROW_CASES if (v,) + c not in ((1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"))])
+                         + [(1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 18, 0, "uniform"), (5, 18, 0, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain")]
+                         + [_soak(v, *c) for v in (1, 2, 3, 4, 5) for c in _LDS_ROW_CASES
+                            if (v,) + c not in ((1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 18, 0, "uniform"), (5, 18, 0, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain"))])
 def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
     """panda_msm_set_accumulate_variant: k_accumulate with the next entry's row staged in LDS (global_load_lds) at five / four waves per
-    SIMD -- the same group element as the oracle says, with tables and on the plain path, uniform and skewed scalars, identity rows"""
+    SIMD (1, 2), rows fetched four lanes to a row (3), the sorted words in 64-byte sectors through LDS forced (4: the built-in kernel of the 9-limb fields) or forbidden (5: rounds 2-5) -- the same group element as the
+    oracle says, with tables and on the plain path, uniform and skewed scalars, identity rows"""
     lib = ffi.load()
     n = 1 << k
     db, ds, dr = DeviceBuffer(n * 64), DeviceBuffer(n * 32), DeviceBuffer(96)
@@ -1728,7 +1730,7 @@ def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
         lib.panda_msm_set_accumulate_variant(0)
         lib.panda_msm_unregister_bases(db.ptr)
     assert (got == po.msm_affine(0, bases, scalars, window_bits=11)).all()
-    assert lib.panda_msm_set_accumulate_variant(4) != 0
+    assert lib.panda_msm_set_accumulate_variant(6) != 0
     for d in (db, ds, dr):
         d.free()
 
