@@ -1702,9 +1702,9 @@ _LDS_ROW_CASES = [(12, 0, "uniform"), (15, 16, "uniform"), (18, 0, "uniform"), (
 
 
 @pytest.mark.parametrize("variant,k,wbits,kind", [(0,) + c for c in _LDS_ROW_CASES]  # variant 0 is the built-in kernel: identity rows, skew, plain path
-                         + [(1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 18, 0, "uniform"), (5, 18, 0, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain")]
+                         + [(1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 15, 16, "uniform"), (5, 15, 16, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain")]
                          + [_soak(v, *c) for v in (1, 2, 3, 4, 5) for c in _LDS_ROW_CASES
-                            if (v,) + c not in ((1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 18, 0, "uniform"), (5, 18, 0, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain"))])
+                            if (v,) + c not in ((1, 15, 16, "uniform"), (2, 13, 14, "all_equal"), (3, 13, 0, "plain"), (4, 15, 16, "uniform"), (5, 15, 16, "uniform"), (5, 13, 14, "all_equal"), (5, 13, 0, "plain"))])
 def test_msm_accumulate_with_the_row_staged_in_lds(gm, variant, k, wbits, kind):
     """panda_msm_set_accumulate_variant: k_accumulate with the next entry's row staged in LDS (global_load_lds) at five / four waves per
     SIMD (1, 2), rows fetched four lanes to a row (3), the sorted words in 64-byte sectors through LDS forced (4: the built-in kernel of the 9-limb fields) or forbidden (5: rounds 2-5) -- the same group element as the
@@ -2365,7 +2365,7 @@ def test_ntt_beyond_three_passes(gm, log_n):
     ffi.check(lib.panda_ntt_execute_bn254_v1(cfg), "ntt")
     assert ntt_passes(log_n) == 3 and flag.value == 1  # three passes: the result is in d_dst (fft.cu:211)
     fwd, other = (d_b, d_a) if flag.value else (d_a, d_b)
-    ks = [1, n - 1, int(rng.integers(0, n))]
+    ks = [1, int(rng.integers(0, n))] if log_n >= 26 else [1, n - 1, int(rng.integers(0, n))]  # O(n) on the host each: 5 s at 2^26
     vals = {k: fwd.to_host(nbytes=32, offset=k * 32) for k in ks}
     for k in ks:
         assert (vals[k] == po.ntt_eval_at(fid, x, om, log_n, k)).all(), k
