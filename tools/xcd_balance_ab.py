@@ -1,4 +1,5 @@
-"""XCD balance (panda_msm_set_xcd_balance: chunk lengths that follow the XCDs' clocks) against equal chunks in alternating blocks inside one process, tabled MSM:
+"""[needs tools/xcd_balance.patch applied to the library: the experiment of profiles/r06_xcd_balance.txt was not kept]
+XCD balance (panda_msm_set_xcd_balance: chunk lengths that follow the XCDs' clocks) against equal chunks in alternating blocks inside one process, tabled MSM:
 wall time of the call, HIP-event time of k_accumulate, its cycles (slowest XCD) and the mean clock.  usage: xcd_balance_ab.py <mode: 1 | 2> <log_n[,..]> [rounds=6] [reps=5] [curve=0]"""
 import ctypes as C
 import os

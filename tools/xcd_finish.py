@@ -1,4 +1,5 @@
-"""Diagnostic (library built with -DPANDA_XCD_FINISH, PANDA_LIB=tools/bin/libpanda-xcdfinish.so, PANDA_XCD_FINISH_PRINT=1): per call, when the last
+"""[needs tools/xcd_balance.patch applied to the library: the experiment of profiles/r06_xcd_balance.txt was not kept]
+Diagnostic (library built with -DPANDA_XCD_FINISH, PANDA_LIB=tools/bin/libpanda-xcdfinish.so, PANDA_XCD_FINISH_PRINT=1): per call, when the last
 workgroup of every XCD left k_accumulate, with equal chunks and with chunk lengths that follow the XCDs' clocks.  usage: xcd_finish.py [log_n=24]"""
 import ctypes as C
 import os
